@@ -1,0 +1,143 @@
+"""Pin the CPU oracle against vectors produced by the reference's own files
+(tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import quant as oq
+
+FP8 = torch.float8_e4m3fn
+
+DECODE = ["decode_gqa4_d128_bf16", "decode_gqa8_d128_bf16", "decode_mha_d128_fp16",
+          "decode_mha_d64_fp16", "decode_gqa4_d128_bf16_shifted"]
+EXTEND = ["extend_gqa4_d128_bf16_noprefix", "extend_gqa4_d128_bf16_prefix",
+          "extend_mha_d64_fp16_prefix", "extend_gqa4_d128_bf16_noncausal"]
+
+
+@pytest.mark.parametrize("name", DECODE)
+def test_decode_oracle_matches_reference(golden_attention, name):
+    c = golden_attention[name]
+    Hq, Hkv = c["q"].shape[1], c["k_cache"].shape[1]
+    kc, vc = c["k_cache"].clone(), c["v_cache"].clone()
+    o = oa.forward_decode(c["q"].reshape(c["q"].shape[0], -1), c["k_new"], c["v_new"], kc, vc,
+                          c["req_to_token"], c["req_pool_indices"], c["seq_lens"], c["out_cache_loc"],
+                          Hq, Hkv, float(c["scaling"]))
+    # same gather + same SDPA call on the same host => bit-identical
+    assert torch.equal(o.view_as(c["o"]), c["o"])
+    # fp32 restatement agrees up to the I/O dtype's rounding
+    o32 = oa.decode_fp32(c["q"], kc, vc, c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                         scaling=float(c["scaling"]))
+    torch.testing.assert_close(o32, c["o"].float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("name", EXTEND)
+def test_extend_oracle_matches_reference(golden_attention, name):
+    c = golden_attention[name]
+    Hq, Hkv = c["q"].shape[1], c["k_cache"].shape[1]
+    kc, vc = c["k_cache"].clone(), c["v_cache"].clone()
+    o = oa.forward_extend(c["q"].reshape(c["q"].shape[0], -1), c["k_new"], c["v_new"], kc, vc,
+                          c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                          c["extend_prefix_lens"], c["extend_seq_lens"], c["out_cache_loc"],
+                          Hq, Hkv, float(c["scaling"]), causal=bool(c["causal"]))
+    assert torch.equal(o.view_as(c["o"]), c["o"])
+    o32 = oa.extend_fp32(c["q"], kc, vc, c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                         c["extend_prefix_lens"], c["extend_seq_lens"], scaling=float(c["scaling"]),
+                         causal=bool(c["causal"]))
+    torch.testing.assert_close(o32, c["o"].float(), atol=1e-2, rtol=1e-2)
+
+
+def test_kv_indices_oracle():
+    # restates test/srt/test_create_kvindices.py:18-49 at small size
+    g = torch.Generator().manual_seed(3)
+    max_batch, ctx, batch = 64, 96, 37
+    req_to_token = torch.arange(max_batch * ctx, dtype=torch.int32).reshape(max_batch, ctx)
+    rpi = torch.randperm(max_batch, generator=g)[:batch]
+    lens = torch.randperm(ctx, generator=g)[:batch].to(torch.int32)   # includes a zero length
+    indptr, idx = oa.kv_indices(req_to_token, rpi, lens)
+    assert indptr.dtype == torch.int32 and idx.dtype == torch.int32
+    assert int(indptr[-1]) == int(lens.sum()) == idx.numel()
+    for i in range(batch):
+        seg = idx[int(indptr[i]): int(indptr[i + 1])]
+        assert torch.equal(seg, req_to_token[rpi[i], : int(lens[i])])
+
+
+def test_merge_state_oracle_is_consistent():
+    # merging two halves of the key set == attention over the whole set
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(3, 4, 32, generator=g)
+    k = torch.randn(50, 4, 32, generator=g)
+    v = torch.randn(50, 4, 32, generator=g)
+    r2t = torch.arange(50, dtype=torch.int32).repeat(3, 1)
+    rpi = torch.arange(3)
+    full, lse = oa.decode_fp32(q, k, v, r2t, rpi, torch.tensor([50, 50, 50]), return_lse=True)
+    a, la = oa.decode_fp32(q, k[:20], v[:20], r2t, rpi, torch.tensor([20] * 3), return_lse=True)
+    r2t_b = (torch.arange(30, dtype=torch.int32) + 20).repeat(3, 1)
+    b, lb = oa.decode_fp32(q, k, v, r2t_b, rpi, torch.tensor([30] * 3), return_lse=True)
+    m, lm = oa.merge_state(a, la, b, lb)
+    torch.testing.assert_close(m, full, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(lm, lse, atol=1e-5, rtol=1e-5)
+    # inf guard (merge_attn_states.cu:66-67)
+    m2, _ = oa.merge_state(a, la, b, torch.full_like(lb, float("inf")))
+    torch.testing.assert_close(m2, a)
+
+
+@pytest.mark.parametrize("name", ["awq_g128_fp16", "awq_gK_bf16"])
+def test_awq_dequant_oracle(golden_quant, name):
+    c = golden_quant[name]
+    W = oq.awq_dequantize(c["qweight"], c["scales"], c["qzeros"], int(c["group"]))
+    assert torch.equal(W, c["W"])
+
+
+@pytest.mark.parametrize("name", ["scaled_mm_bf16_bias", "scaled_mm_fp16"])
+def test_scaled_mm_oracle(golden_quant, name):
+    c = golden_quant[name]
+    o = oq.scaled_mm(c["a"].view(FP8), c["b_nk"].view(FP8).t(), c["scale_a"], c["scale_b"],
+                     c["o"].dtype, c.get("bias"))
+    assert torch.equal(o, c["o"])
+
+
+def test_per_tensor_and_token_quant_oracle(golden_quant):
+    c = golden_quant["per_tensor_dynamic"]
+    q, s = oq.per_tensor_quant_fp8(c["x"])
+    assert torch.equal(s, c["scale"]) and torch.equal(q.view(torch.uint8), c["q"])
+    c = golden_quant["per_tensor_static"]
+    q, s = oq.per_tensor_quant_fp8(c["x"], c["scale"])
+    assert torch.equal(q.view(torch.uint8), c["q"])
+    c = golden_quant["per_token"]
+    q, s = oq.per_token_quant_fp8(c["x"])
+    assert torch.equal(s.flatten(), c["scale"]) and torch.equal(q.view(torch.uint8), c["q"])
+
+
+def test_input_to_float8_oracle(golden_quant):
+    c = golden_quant["input_to_float8"]
+    q, inv = oq.input_to_float8(c["x"])
+    assert torch.equal(q.view(torch.uint8), c["q"]) and torch.equal(inv, c["inv_scale"])
+
+
+def test_fp8_linear_oracle(golden_quant):
+    # per-tensor x per-tensor: the reference runs torch._scaled_mm (fp8_utils.py:715); its bf16 result
+    # can differ from the fp32-spelled product by bf16 rounding of the epilogue order only.
+    c = golden_quant["fp8_linear_per_tensor"]
+    y = oq.fp8_linear(c["x"], c["w_nk"].view(FP8).t(), c["w_scale"], None, c["bias"])
+    torch.testing.assert_close(y.float(), c["y"].float(), atol=2e-3, rtol=1.6e-2)
+    c = golden_quant["fp8_linear_per_token_fallback"]
+    y = oq.fp8_linear(c["x"], c["w_nk"].view(FP8).t(), c["w_scale"], None, c["bias"], per_token=True)
+    torch.testing.assert_close(y.float(), c["y"].float(), atol=2e-3, rtol=1.6e-2)
+
+
+def test_gptq_dequant_self_consistency():
+    # PARITY UNPINNED (vllm arithmetic not under /root/reference): check only the packing convention
+    g = torch.Generator().manual_seed(9)
+    K, N, gs = 256, 32, 128
+    w = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int32)
+    z = torch.randint(0, 15, (K // gs, N), generator=g, dtype=torch.int32)
+    s = torch.rand(K // gs, N, generator=g).to(torch.float16)
+    qweight = torch.zeros(K // 8, N, dtype=torch.int32)
+    for i in range(8):
+        qweight |= w[i::8] << (4 * i)
+    qzeros = torch.zeros(K // gs, N // 8, dtype=torch.int32)
+    for j in range(8):
+        qzeros |= z[:, j::8] << (4 * j)
+    W = oq.gptq_dequantize(qweight, s, qzeros, None, gs)
+    ref = (w - (z + 1).repeat_interleave(gs, 0)) * s.repeat_interleave(gs, 0)
+    assert torch.equal(W, ref)
