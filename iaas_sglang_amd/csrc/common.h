@@ -1,0 +1,75 @@
+// Shared device/host helpers for the gfx950 hot-path kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mi_hotpath.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MI_WAVE 64
+
+// ---- error plumbing (host) --------------------------------------------------
+void mi_set_error(const char* fmt, ...);
+#define MI_FAIL(code, ...)        \
+  do {                            \
+    mi_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+#define MI_CHECK_ARG(cond)                                                          \
+  do {                                                                              \
+    if (!(cond)) MI_FAIL(MI_ERR_INVALID, "%s: invalid argument: %s", __func__, #cond); \
+  } while (0)
+#define MI_CHECK_LAUNCH()                                                            \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess)                                                           \
+      MI_FAIL(MI_ERR_LAUNCH, "%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- element traits ---------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  typedef bf16x8 vec8;
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<f16_t> {
+  typedef f16x8 vec8;
+  static __device__ __forceinline__ float lo(uint32_t w) {
+    return (float)__builtin_bit_cast(f16_t, (uint16_t)(w & 0xffffu));
+  }
+  static __device__ __forceinline__ float hi(uint32_t w) {
+    return (float)__builtin_bit_cast(f16_t, (uint16_t)(w >> 16));
+  }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  T x = (T)a, y = (T)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+// broadcast lane `N` of each 16-lane row to the whole row (gfx90a+ DPP row_newbcast)
+template <int N> __device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

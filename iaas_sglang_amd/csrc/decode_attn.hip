@@ -1,0 +1,383 @@
+// Split-KV token (decode) attention over the paged KV pool -- gfx950, wave64.
+//
+// One WAVE owns one (request b, kv head hk, kv split s) and all `group` query heads that
+// share that kv head; the W waves of a workgroup are W consecutive kv heads of the same
+// (b, s), so the 256-B per-head segments of one 2-KB token slot are fetched together.
+// No LDS, no barriers: waves are independent.
+//
+//   S^T[token][qhead] = K_tile[16 tok x D] . Q^T        MFMA 16x16x32 (K rows straight from HBM
+//                                                        into the A fragment: lane -> token l&15,
+//                                                        dims 32*ks + 8*(l>>4) .. +8)
+//   online softmax in the MFMA C layout (lane: qhead = l&15, tokens 4*(l>>4)+r), fp32,
+//   deferred rescale (only when the running max grows by > 2^8)
+//   O[qhead][d] += P . V                                  VALU fp32 FMA; V rows read fully
+//                                                        coalesced (16 lanes x 16 B = one 256-B
+//                                                        row), P broadcast inside each 16-lane
+//                                                        row by DPP row_newbcast
+// HBM-bound: algorithmic bytes = 2 * tokens * Hkv * D * sizeof(T) (+ indices, q, o).
+#include "common.h"
+
+struct DecodeParams {
+  const void* q;
+  const void* k_buf;
+  const void* v_buf;
+  void* o;
+  const int32_t* kv_indptr;
+  const int32_t* kv_indices;
+  float* ws_o;   // [B][Hq][splits][D]
+  float* ws_ml;  // [B][Hq][splits][2]
+  int32_t num_q_heads, num_kv_heads, group, num_splits;
+  int64_t stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot;
+  float scale_log2;  // sm_scale * log2(e)   (logit_cap == 0)
+  float sm_scale, logit_cap;
+};
+
+#define RESCALE_THR 8.0f
+
+template <int N> struct IntC { static constexpr int value = N; };
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <typename T, int D, int G, int W>
+__global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams p) {
+  constexpr int KS = D / 32;       // MFMA k-steps over the head dim
+  constexpr int LPT = D / 8;       // lanes per V token row (16 B per lane)
+  constexpr int TPR = 16 / LPT;    // tokens per 16-lane row per V load (1: D=128, 2: D=64)
+  constexpr int NLOAD = 4 / TPR;   // V loads per 16-token tile
+  typedef typename Elem<T>::vec8 vec8;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = lane >> 4, col = lane & 15;
+  const int s = blockIdx.x;
+  const int hk = blockIdx.y * W + wave;
+  const int b = blockIdx.z;
+  if (hk >= p.num_kv_heads) return;
+  const int group = p.group;
+  const int nsplit = p.num_splits;
+
+  const int32_t base = p.kv_indptr[b];
+  const int32_t S = p.kv_indptr[b + 1] - base;
+  int32_t per = (S + nsplit - 1) / nsplit;
+  per = (per + 15) & ~15;
+  const int32_t start = s * per;
+  const int32_t end = min(S, start + per);
+  const int hq0 = hk * group;
+
+  if (start >= end) {  // empty split (or empty request)
+    if (nsplit > 1) {
+      if (row == 0 && col < group) {
+        float* ml = p.ws_ml + (((int64_t)b * p.num_q_heads + hq0 + col) * nsplit + s) * 2;
+        ml[0] = -INFINITY;
+        ml[1] = 0.f;
+      }
+    } else if (row == 0 && col < LPT) {
+      for (int g = 0; g < group; ++g) {
+        T* o = (T*)p.o + (int64_t)b * p.stride_o_tok + (int64_t)(hq0 + g) * D + col * 8;
+        *(uint4*)o = make_uint4(0, 0, 0, 0);
+      }
+    }
+    return;
+  }
+
+  // ---- Q fragments (B operand): lane -> qhead col, dims 32*ks + 8*row .. +8
+  vec8 qf[KS];
+  {
+    const T* q = (const T*)p.q + (int64_t)b * p.stride_q_tok + (int64_t)(hq0 + col) * D + row * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (col < group) z = *(const uint4*)(q + ks * 32);
+      qf[ks] = __builtin_bit_cast(vec8, z);
+    }
+  }
+
+  const int32_t* idx = p.kv_indices + base;
+  const T* kb = (const T*)p.k_buf + (int64_t)hk * D + row * 8;
+  const T* vb = (const T*)p.v_buf + (int64_t)hk * D + (col % LPT) * 8;
+  const int vtok = 4 * row + (col / LPT);  // + TPR * i
+
+  float acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  struct Tile {
+    vec8 kf[KS];
+    uint4 vv[NLOAD];
+  };
+  auto load_idx = [&](int32_t t0, int32_t& ik, int32_t (&iv)[NLOAD]) {
+    ik = idx[min(t0 + col, end - 1)];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) iv[i] = idx[min(t0 + vtok + TPR * i, end - 1)];
+  };
+  auto load_tile = [&](Tile& t, int32_t ik, const int32_t (&iv)[NLOAD]) {
+    const T* kp = kb + (int64_t)ik * p.stride_k_slot;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) t.kf[ks] = __builtin_bit_cast(vec8, *(const uint4*)(kp + ks * 32));
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) t.vv[i] = *(const uint4*)(vb + (int64_t)iv[i] * p.stride_v_slot);
+  };
+
+  auto compute = [&](const Tile& t, int32_t t0) {
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sacc = Elem<T>::mfma16(t.kf[ks], qf[ks], sacc);
+    float sc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x;
+      if (p.logit_cap > 0.f) {
+        float y = sacc[r] * p.sm_scale / p.logit_cap;
+        float e = __expf(2.f * y);
+        x = p.logit_cap * (1.f - 2.f / (e + 1.f)) * 1.4426950408889634f;
+      } else {
+        x = sacc[r] * p.scale_log2;
+      }
+      sc[r] = (t0 + 4 * row + r < end) ? x : -INFINITY;
+    }
+    float tm = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    tm = fmaxf(tm, __shfl_xor(tm, 16));
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    const bool grow = (col < group) && (tm > m + RESCALE_THR);
+    if (__any(grow)) {
+      const float mn = fmaxf(m, tm);
+      const float alpha = fast_exp2(m - mn);  // m = -inf on the first tile -> 0
+      m = mn;
+      lsum *= alpha;
+      static_for<0, G>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        const float a = row_bcast<g>(alpha);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] *= a;
+      });
+    }
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = fast_exp2(sc[r] - m);
+      lsum += pr[r];
+    }
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      float vf[8];
+      const uint32_t w[4] = {t.vv[i].x, t.vv[i].y, t.vv[i].z, t.vv[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vf[2 * j] = Elem<T>::lo(w[j]);
+        vf[2 * j + 1] = Elem<T>::hi(w[j]);
+      }
+      static_for<0, G>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        float pg;
+        if constexpr (TPR == 1) {
+          pg = row_bcast<g>(pr[i]);
+        } else {
+          const float p0 = row_bcast<g>(pr[2 * i]);
+          const float p1 = row_bcast<g>(pr[2 * i + 1]);
+          pg = (col / LPT) ? p1 : p0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(pg, vf[j], acc[g][j]);
+      });
+    }
+  };
+
+  // ---- main loop, 16 tokens per tile, next tile's K/V and the one after's indices in flight
+  Tile ta, tb;
+  int32_t ik, iv[NLOAD];
+  load_idx(start, ik, iv);
+  load_tile(ta, ik, iv);
+  if (start + 16 < end) load_idx(start + 16, ik, iv);
+  for (int32_t t0 = start; t0 < end; t0 += 32) {
+    const bool has_b = t0 + 16 < end;
+    if (has_b) {
+      load_tile(tb, ik, iv);
+      if (t0 + 32 < end) load_idx(t0 + 32, ik, iv);
+    }
+    compute(ta, t0);
+    if (!has_b) break;
+    if (t0 + 32 < end) {
+      load_tile(ta, ik, iv);
+      if (t0 + 48 < end) load_idx(t0 + 48, ik, iv);
+    }
+    compute(tb, t0 + 16);
+  }
+
+  // ---- combine the partial sums held by the 4 lane rows (and the TPR token sub-rows)
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = acc[g][j];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      if constexpr (TPR == 2) x += __shfl_xor(x, 8);
+      acc[g][j] = x;
+    }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+
+  static_for<0, G>([&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    const float lg = row_bcast<g>(lsum);
+    const float mg = row_bcast<g>(m);
+    if (g < group && row == 0 && col < LPT) {
+      const int64_t hq = hq0 + g;
+      if (nsplit == 1) {
+        const float inv = 1.f / lg;
+        uint4 out;
+        out.x = pack2<T>(acc[g][0] * inv, acc[g][1] * inv);
+        out.y = pack2<T>(acc[g][2] * inv, acc[g][3] * inv);
+        out.z = pack2<T>(acc[g][4] * inv, acc[g][5] * inv);
+        out.w = pack2<T>(acc[g][6] * inv, acc[g][7] * inv);
+        *(uint4*)((T*)p.o + (int64_t)b * p.stride_o_tok + hq * D + col * 8) = out;
+      } else {
+        const int64_t slot = ((int64_t)b * p.num_q_heads + hq) * nsplit + s;
+        float4* wo = (float4*)(p.ws_o + slot * D + col * 8);
+        wo[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        wo[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+        if (col == 0) {
+          p.ws_ml[slot * 2] = mg;
+          p.ws_ml[slot * 2 + 1] = lg;
+        }
+      }
+    }
+  });
+}
+
+// ---- stage 2: merge the per-split partials (one wave per (b, qhead)) -------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ ws_o,
+                                                           const float* __restrict__ ws_ml, T* o,
+                                                           int64_t n_bh, int32_t num_q_heads,
+                                                           int32_t nsplit, int64_t stride_o_tok) {
+  constexpr int EPL = D / 64 > 0 ? D / 64 : 1;  // elements per lane
+  const int lane = threadIdx.x & 63;
+  const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= n_bh) return;
+  const float* ml = ws_ml + bh * nsplit * 2;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ml[2 * s]);
+  float L = 0.f, acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+  const bool active = lane * EPL < D;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = fast_exp2(ml[2 * s] - M);
+    L += ml[2 * s + 1] * w;
+    if (active) {
+      const float* po = ws_o + (bh * nsplit + s) * D + lane * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] += po[e] * w;
+    }
+  }
+  if (active) {
+    const int64_t b = bh / num_q_heads, h = bh % num_q_heads;
+    T* out = o + b * stride_o_tok + h * D + lane * EPL;
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) out[e] = (T)(acc[e] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+extern "C" int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_heads,
+                                                  int64_t v_head_dim, int64_t num_splits) {
+  if (num_splits <= 1) return 0;
+  return batch * num_q_heads * num_splits * (v_head_dim + 2) * (int64_t)sizeof(float);
+}
+
+template <typename T, int D, int G, int W>
+static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
+  dim3 grid((unsigned)p.num_splits, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)batch);
+  decode_attn_kernel<T, D, G, W><<<grid, W * 64, 0, st>>>(p);
+}
+
+template <typename T, int D, int G>
+static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st) {
+  const int h = p.num_kv_heads;
+  if (h % 8 == 0) launch_decode<T, D, G, 8>(p, batch, st);
+  else if (h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
+  else if (h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
+  else launch_decode<T, D, G, 1>(p, batch, st);
+}
+
+template <typename T, int D>
+static int launch_decode_g(const DecodeParams& p, int64_t batch, hipStream_t st) {
+  const int g = p.group;
+  if (g == 1) launch_decode_w<T, D, 1>(p, batch, st);
+  else if (g == 2) launch_decode_w<T, D, 2>(p, batch, st);
+  else if (g <= 4) launch_decode_w<T, D, 4>(p, batch, st);
+  else if (g <= 8) launch_decode_w<T, D, 8>(p, batch, st);
+  else if (g <= 16) launch_decode_w<T, D, 16>(p, batch, st);
+  else return MI_ERR_UNSUPPORTED;
+  return MI_OK;
+}
+
+extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
+                              const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
+                              int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                              int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                              int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                              float logit_cap, int64_t num_splits, int dtype, void* stream) {
+  MI_CHECK_ARG(batch >= 0);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(q && k_buf && v_buf && o && kv_indptr && kv_indices);
+  MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
+  MI_CHECK_ARG(num_splits >= 1 && num_splits <= 65535 && batch <= 65535);
+  MI_CHECK_ARG(num_splits == 1 || workspace != nullptr);
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
+  if (head_dim != 64 && head_dim != 128)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_decode_attn: head_dim %lld not supported (64, 128)", (long long)head_dim);
+  // 16-byte vector accesses on q/k/v/o rows
+  MI_CHECK_ARG(stride_q_tok % 8 == 0 && stride_o_tok % 8 == 0 && stride_k_slot % 8 == 0 &&
+               stride_v_slot % 8 == 0);
+  MI_CHECK_ARG((((uintptr_t)q | (uintptr_t)k_buf | (uintptr_t)v_buf | (uintptr_t)o) & 15) == 0);
+  MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+
+  DecodeParams p;
+  p.q = q; p.k_buf = k_buf; p.v_buf = v_buf; p.o = o;
+  p.kv_indptr = kv_indptr; p.kv_indices = kv_indices;
+  p.ws_o = (float*)workspace;
+  p.ws_ml = p.ws_o ? p.ws_o + batch * num_q_heads * num_splits * head_dim : nullptr;
+  p.num_q_heads = (int32_t)num_q_heads; p.num_kv_heads = (int32_t)num_kv_heads;
+  p.group = (int32_t)(num_q_heads / num_kv_heads); p.num_splits = (int32_t)num_splits;
+  p.stride_q_tok = stride_q_tok; p.stride_o_tok = stride_o_tok;
+  p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
+  p.sm_scale = sm_scale; p.logit_cap = logit_cap;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+
+  int rc;
+  if (dtype == MI_BF16)
+    rc = head_dim == 128 ? launch_decode_g<bf16_t, 128>(p, batch, st) : launch_decode_g<bf16_t, 64>(p, batch, st);
+  else
+    rc = head_dim == 128 ? launch_decode_g<f16_t, 128>(p, batch, st) : launch_decode_g<f16_t, 64>(p, batch, st);
+  if (rc != MI_OK) MI_FAIL(rc, "mi_decode_attn: group size %d not supported (<= 16)", p.group);
+  MI_CHECK_LAUNCH();
+
+  if (num_splits > 1) {
+    const int64_t n_bh = batch * num_q_heads;
+    const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
+    if (dtype == MI_BF16) {
+      if (head_dim == 128)
+        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+      else
+        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+    } else {
+      if (head_dim == 128)
+        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+      else
+        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+    }
+    MI_CHECK_LAUNCH();
+  }
+  return MI_OK;
+}

@@ -1,0 +1,164 @@
+// Integer / byte-moving kernels of the hot path: kv_indptr scan, kv_indices gather,
+// KV-pool scatter.  All bit-exact; HBM/latency-bound, no MFMA.
+#include "common.h"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void mi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
+extern "C" int mi_device_cu_count(void) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}
+
+// ---------------------------------------------------------------- kv_indptr
+// One workgroup of 1024 threads scans up to any batch in chunks (batch is <= a few thousand).
+template <typename L>
+__global__ __launch_bounds__(1024) void kv_indptr_kernel(const L* __restrict__ lens,
+                                                         int32_t* __restrict__ indptr, int64_t batch) {
+  __shared__ int32_t wave_sum[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    carry_s = 0;
+    indptr[0] = 0;
+  }
+  __syncthreads();
+  for (int64_t base = 0; base < batch; base += 1024) {
+    int64_t i = base + tid;
+    int32_t v = (i < batch) ? (int32_t)lens[i] : 0;
+    int32_t x = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sum[wave] = x;
+    __syncthreads();
+    int32_t prefix = carry_s;
+    for (int w = 0; w < wave; ++w) prefix += wave_sum[w];
+    if (i < batch) indptr[i + 1] = prefix + x;
+    __syncthreads();
+    if (tid == 1023) carry_s = prefix + x;
+    __syncthreads();
+  }
+}
+
+extern "C" int mi_kv_indptr(const void* lens, int lens_is_i64, int32_t* kv_indptr, int64_t batch,
+                            void* stream) {
+  MI_CHECK_ARG(kv_indptr != nullptr && batch >= 0);
+  MI_CHECK_ARG(batch == 0 || lens != nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  if (lens_is_i64)
+    kv_indptr_kernel<int64_t><<<1, 1024, 0, s>>>((const int64_t*)lens, kv_indptr, batch);
+  else
+    kv_indptr_kernel<int32_t><<<1, 1024, 0, s>>>((const int32_t*)lens, kv_indptr, batch);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------- kv_indices
+// grid (chunks, batch): each workgroup copies a 1024-int slice of one request's row.
+template <typename L>
+__global__ __launch_bounds__(256) void kv_indices_kernel(const int32_t* __restrict__ req_to_token,
+                                                         int64_t stride,
+                                                         const int64_t* __restrict__ req_pool_indices,
+                                                         const L* __restrict__ lens,
+                                                         const int32_t* __restrict__ kv_indptr,
+                                                         const int32_t* __restrict__ kv_start_idx,
+                                                         int32_t* __restrict__ kv_indices) {
+  const int b = blockIdx.y;
+  const int64_t len = (int64_t)lens[b];
+  const int64_t start = kv_start_idx ? (int64_t)kv_start_idx[b] : 0;
+  const int32_t* src = req_to_token + req_pool_indices[b] * stride + start;
+  int32_t* dst = kv_indices + kv_indptr[b];
+  for (int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x; j < len; j += (int64_t)gridDim.x * 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t jj = j + u * 256;
+      if (jj < len) dst[jj] = src[jj];
+    }
+  }
+}
+
+extern "C" int mi_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                             const int64_t* req_pool_indices, const void* lens, int lens_is_i64,
+                             const int32_t* kv_indptr, const int32_t* kv_start_idx,
+                             int32_t* kv_indices, int64_t batch, void* stream) {
+  MI_CHECK_ARG(batch >= 0 && batch <= 65535);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(req_to_token && req_pool_indices && lens && kv_indptr && kv_indices);
+  MI_CHECK_ARG(req_to_token_stride > 0);
+  hipStream_t s = (hipStream_t)stream;
+  // enough chunks that a 128 x 2048 batch fills the chip; longer rows grid-stride.
+  int chunks = (int)(cdiv64(req_to_token_stride, 1024) < 8 ? cdiv64(req_to_token_stride, 1024) : 8);
+  if (chunks < 1) chunks = 1;
+  dim3 grid(chunks, (unsigned)batch);
+  if (lens_is_i64)
+    kv_indices_kernel<int64_t><<<grid, 256, 0, s>>>(req_to_token, req_to_token_stride, req_pool_indices,
+                                                    (const int64_t*)lens, kv_indptr, kv_start_idx,
+                                                    kv_indices);
+  else
+    kv_indices_kernel<int32_t><<<grid, 256, 0, s>>>(req_to_token, req_to_token_stride, req_pool_indices,
+                                                    (const int32_t*)lens, kv_indptr, kv_start_idx,
+                                                    kv_indices);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------- kv_write
+// One wave per (token, k|v) row; 16 B per lane when rows are 16-B granular, else 2 B elements.
+__global__ __launch_bounds__(256) void kv_write_kernel(uint16_t* __restrict__ k_cache,
+                                                       uint16_t* __restrict__ v_cache,
+                                                       const int64_t* __restrict__ loc,
+                                                       const uint16_t* __restrict__ k,
+                                                       const uint16_t* __restrict__ v, int64_t tokens,
+                                                       int64_t row_k, int64_t row_v, int64_t cs_k,
+                                                       int64_t cs_v, int64_t ss_k, int64_t ss_v,
+                                                       int vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= tokens * 2) return;
+  const int64_t t = w >> 1;
+  const bool is_v = w & 1;
+  const int64_t slot = loc[t];
+  const uint16_t* src = is_v ? v + t * ss_v : k + t * ss_k;
+  uint16_t* dst = is_v ? v_cache + slot * cs_v : k_cache + slot * cs_k;
+  const int64_t n = is_v ? row_v : row_k;
+  if (vec_ok) {
+    const uint4* s4 = (const uint4*)src;
+    uint4* d4 = (uint4*)dst;
+    for (int64_t i = lane; i < n / 8; i += 64) d4[i] = s4[i];
+  } else {
+    for (int64_t i = lane; i < n; i += 64) dst[i] = src[i];
+  }
+}
+
+extern "C" int mi_kv_write(void* k_cache, void* v_cache, const int64_t* loc, const void* k,
+                           const void* v, int64_t tokens, int64_t row_elems_k, int64_t row_elems_v,
+                           int64_t cache_stride_k, int64_t cache_stride_v, int64_t src_stride_k,
+                           int64_t src_stride_v, int dtype, void* stream) {
+  MI_CHECK_ARG(tokens >= 0);
+  if (tokens == 0) return MI_OK;
+  MI_CHECK_ARG(k_cache && v_cache && loc && k && v);
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
+  MI_CHECK_ARG(row_elems_k > 0 && row_elems_v > 0);
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  int vec_ok = (row_elems_k % 8 == 0) && (row_elems_v % 8 == 0) && (cache_stride_k % 8 == 0) &&
+               (cache_stride_v % 8 == 0) && (src_stride_k % 8 == 0) && (src_stride_v % 8 == 0) &&
+               al16(k_cache) && al16(v_cache) && al16(k) && al16(v);
+  int64_t waves = tokens * 2;
+  kv_write_kernel<<<(unsigned)cdiv64(waves, 4), 256, 0, (hipStream_t)stream>>>(
+      (uint16_t*)k_cache, (uint16_t*)v_cache, loc, (const uint16_t*)k, (const uint16_t*)v, tokens,
+      row_elems_k, row_elems_v, cache_stride_k, cache_stride_v, src_stride_k, src_stride_v, vec_ok);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}

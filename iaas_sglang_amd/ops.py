@@ -1,0 +1,218 @@
+"""Thin torch-tensor -> C-ABI wrappers.  PyTorch is only plumbing here (device memory,
+the current HIP stream); every computation happens in libmi_hotpath.so.
+
+All wrappers enqueue on ``torch.cuda.current_stream()`` and never synchronise, so they
+can be captured into a hipGraph (torch.cuda.graph) as long as the caller preallocates.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import (MI_BF16, MI_FP16, MI_SCALE_ROW, MI_SCALE_TENSOR, MI_W4_AWQ, MI_W4_GPTQ,
+                   MiHotpathError, check, lib)
+
+FP8_DTYPE = torch.float8_e4m3fn  # gfx950 = OCP e4m3fn
+_DT = {torch.bfloat16: MI_BF16, torch.float16: MI_FP16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise MiHotpathError(f"unsupported dtype {t.dtype} (bf16 / fp16 only)") from None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MiHotpathError("hot-path ops need device tensors (no CPU path exists)")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cu_count() -> int:
+    return lib.mi_device_cu_count()
+
+
+# ------------------------------------------------------------------ integer path
+def kv_indptr(lens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [B+1] exclusive-scan of lens (int32 or int64)."""
+    B = lens.shape[0]
+    assert lens.dtype in (torch.int32, torch.int64) and lens.is_contiguous()
+    if out is None:
+        out = torch.empty(B + 1, dtype=torch.int32, device=lens.device)
+    assert out.dtype == torch.int32 and out.numel() >= B + 1
+    check(lib.mi_kv_indptr(_ptr(lens), int(lens.dtype == torch.int64), _ptr(out), B, _stream()), "mi_kv_indptr")
+    return out[: B + 1]
+
+
+def kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, lens: torch.Tensor,
+               kv_indptr_t: torch.Tensor, out: torch.Tensor,
+               kv_start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gather req_to_token row slices into the flat kv_indices (int32), bit-exact."""
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and req_pool_indices.is_contiguous()
+    assert lens.dtype in (torch.int32, torch.int64) and lens.is_contiguous()
+    assert kv_indptr_t.dtype == torch.int32 and out.dtype == torch.int32
+    if kv_start_idx is not None:
+        assert kv_start_idx.dtype == torch.int32
+    B = req_pool_indices.shape[0]
+    check(lib.mi_kv_indices(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _ptr(lens),
+                            int(lens.dtype == torch.int64), _ptr(kv_indptr_t), _ptr(kv_start_idx), _ptr(out),
+                            B, _stream()), "mi_kv_indices")
+    return out
+
+
+def kv_write(k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor, k: torch.Tensor,
+             v: torch.Tensor) -> None:
+    """k_cache[loc] = k ; v_cache[loc] = v   (set_kv_buffer)."""
+    assert loc.dtype == torch.int64 and loc.is_contiguous()
+    T = loc.shape[0]
+    k = k.reshape(T, -1)
+    v = v.reshape(T, -1)
+    assert k.dtype == k_cache.dtype and v.dtype == v_cache.dtype and k.stride(1) == 1 and v.stride(1) == 1
+    row_k, row_v = k.shape[1], v.shape[1]
+    assert k_cache[0].numel() == row_k and v_cache[0].numel() == row_v
+    assert k_cache[0].is_contiguous() and v_cache[0].is_contiguous()
+    check(lib.mi_kv_write(_ptr(k_cache), _ptr(v_cache), _ptr(loc), _ptr(k), _ptr(v), T, row_k, row_v,
+                          k_cache.stride(0), v_cache.stride(0), k.stride(0), v.stride(0), _dt(k_cache),
+                          _stream()), "mi_kv_write")
+
+
+# --------------------------------------------------------------------- attention
+def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_splits: int) -> int:
+    return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4
+
+
+def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o: torch.Tensor,
+                     kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, sm_scale: float,
+                     logit_cap: float = 0.0, num_splits: int = 1,
+                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q,o [B,Hq,D]; k_buf,v_buf [slots,Hkv,D]; split-KV token attention."""
+    B, Hq, D = q.shape
+    Hkv = k_buf.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == D and o.stride(2) == 1 and o.stride(1) == D
+    assert k_buf.stride(2) == 1 and k_buf.stride(1) == D and v_buf.stride(2) == 1 and v_buf.stride(1) == D
+    assert k_buf.dtype == q.dtype and v_buf.dtype == q.dtype and o.dtype == q.dtype
+    assert kv_indptr_t.dtype == torch.int32 and kv_indices_t.dtype == torch.int32
+    if num_splits > 1:
+        need = decode_workspace_numel(B, Hq, D, num_splits)
+        assert workspace is not None and workspace.dtype == torch.float32 and workspace.numel() >= need
+    check(lib.mi_decode_attn(_ptr(q), _ptr(k_buf), _ptr(v_buf), _ptr(o), _ptr(kv_indptr_t), _ptr(kv_indices_t),
+                             _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0), o.stride(0),
+                             k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap),
+                             int(num_splits), _dt(q), _stream()), "mi_decode_attn")
+    return o
+
+
+def extend_attention(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
+                     k_buf: torch.Tensor, v_buf: torch.Tensor, qo_indptr: torch.Tensor,
+                     kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, max_extend_len: int,
+                     sm_scale: float, logit_cap: float = 0.0, causal: bool = True,
+                     sliding_window: int = -1) -> torch.Tensor:
+    """q,o [E,Hq,D]; k_ext,v_ext [E,Hkv,D]; prefix read from k_buf/v_buf through kv_indices."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, o, k_ext, v_ext, k_buf, v_buf):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    assert qo_indptr.dtype == torch.int32 and kv_indptr_t.dtype == torch.int32
+    assert kv_indices_t.dtype == torch.int32
+    check(lib.mi_extend_attn(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o), _ptr(k_buf), _ptr(v_buf),
+                             _ptr(qo_indptr), _ptr(kv_indptr_t), _ptr(kv_indices_t), B, int(max_extend_len),
+                             Hq, Hkv, D, q.stride(0), o.stride(0), k_ext.stride(0), v_ext.stride(0),
+                             k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap), int(causal),
+                             int(sliding_window), _dt(q), _stream()), "mi_extend_attn")
+    return o
+
+
+def merge_state(o_a, lse_a, o_b, lse_b, out=None, out_lse=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    n, h, d = o_a.shape
+    assert o_a.is_contiguous() and o_b.is_contiguous() and lse_a.is_contiguous() and lse_b.is_contiguous()
+    assert lse_a.dtype == torch.float32 and lse_b.dtype == torch.float32
+    out = torch.empty_like(o_a) if out is None else out
+    out_lse = torch.empty_like(lse_a) if out_lse is None else out_lse
+    check(lib.mi_merge_state(_ptr(o_a), _ptr(lse_a), _ptr(o_b), _ptr(lse_b), _ptr(out), _ptr(out_lse), n, h, d,
+                             _dt(o_a), _stream()), "mi_merge_state")
+    return out, out_lse
+
+
+# --------------------------------------------------------------------------- FP8
+def fp8_quant_per_tensor(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                         out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scale None -> dynamic (scale = absmax/448 written to a new fp32 [1]); else static."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    is_static = scale is not None
+    if scale is None:
+        scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    assert scale.dtype == torch.float32 and scale.numel() == 1
+    out = torch.empty(M, K, dtype=FP8_DTYPE, device=x.device) if out is None else out
+    check(lib.mi_fp8_quant_per_tensor(_ptr(x), _ptr(out), _ptr(scale), M, K, x.stride(0), int(is_static), _dt(x),
+                                      _stream()), "mi_fp8_quant_per_tensor")
+    return out, scale
+
+
+def fp8_quant_per_token(x: torch.Tensor, out: Optional[torch.Tensor] = None,
+                        scales: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    out = torch.empty(M, K, dtype=FP8_DTYPE, device=x.device) if out is None else out
+    scales = torch.empty(M, 1, dtype=torch.float32, device=x.device) if scales is None else scales
+    check(lib.mi_fp8_quant_per_token(_ptr(x), _ptr(out), _ptr(scales), M, K, x.stride(0), _dt(x), _stream()),
+          "mi_fp8_quant_per_token")
+    return out, scales
+
+
+def fp8_gemm(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+             out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a fp8 [M,K]; b_kn fp8 [K,N] *column-major* (the `.t()` view of [N,K] storage, as the
+    reference stores it); scale_a 1 or M values; scale_b 1 or N values."""
+    M, K = a.shape
+    K2, N = b_kn.shape
+    assert K == K2 and a.dtype == FP8_DTYPE and b_kn.dtype == FP8_DTYPE
+    assert a.stride(1) == 1 and b_kn.stride(0) == 1, "b must be the [K,N] view of [N,K] row-major storage"
+    sa_mode = MI_SCALE_TENSOR if scale_a.numel() == 1 else MI_SCALE_ROW
+    sb_mode = MI_SCALE_TENSOR if scale_b.numel() == 1 else MI_SCALE_ROW
+    assert sa_mode == MI_SCALE_TENSOR or scale_a.numel() == M
+    assert sb_mode == MI_SCALE_TENSOR or scale_b.numel() == N
+    assert scale_a.dtype == torch.float32 and scale_b.dtype == torch.float32
+    out = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
+    if bias is not None:
+        assert bias.dtype == out_dtype and bias.numel() == N and bias.is_contiguous()
+    check(lib.mi_fp8_gemm(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(bias), _ptr(out), M, N, K,
+                          a.stride(0), b_kn.stride(1), out.stride(0), sa_mode, sb_mode, _DT[out_dtype],
+                          _stream()), "mi_fp8_gemm")
+    return out
+
+
+# -------------------------------------------------------------------------- int4
+def w4a16_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+               group_size: int, layout: int, g_idx: Optional[torch.Tensor] = None,
+               bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.dim() == 2 and x.is_contiguous()
+    M, K = x.shape
+    N = scales.shape[1]
+    assert qweight.dtype == torch.int32 and qzeros.dtype == torch.int32 and scales.dtype == x.dtype
+    assert qweight.is_contiguous() and qzeros.is_contiguous() and scales.is_contiguous()
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    check(lib.mi_w4a16_gemm(_ptr(x), _ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(bias),
+                            _ptr(out), M, N, K, int(group_size), int(layout), _dt(x), _stream()), "mi_w4a16_gemm")
+    return out
+
+
+def w4_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, group_size: int,
+                  layout: int, g_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    N = scales.shape[1]
+    K = qweight.shape[0] if layout == MI_W4_AWQ else qweight.shape[0] * 8
+    out = torch.empty(K, N, dtype=scales.dtype, device=scales.device)
+    check(lib.mi_w4_dequantize(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(out), N, K,
+                               int(group_size), int(layout), _dt(scales), _stream()), "mi_w4_dequantize")
+    return out

@@ -1,0 +1,162 @@
+/*
+ * mi_hotpath.h -- C ABI of the MI355X (gfx950) hot-path library  libmi_hotpath.so
+ *
+ * Drop-in boundary for the reference's batched prefill/decode hot path (SURVEY.md
+ * section 8b).  Every entry point replaces one native/Triton op the reference's
+ * Python calls; the citation after "replaces:" is path:line under /root/reference.
+ *
+ * Conventions (all functions):
+ *   - plain C: raw DEVICE pointers, explicit element strides, int64 sizes, a
+ *     hipStream_t passed as void*; no torch / ATen types;
+ *   - return 0 on success, <0 on error (MI_ERR_*); mi_last_error() gives the text
+ *     (thread-local); nothing is thrown;
+ *   - never allocate, never synchronise, never touch the default stream: work is
+ *     enqueued on `stream` only, so every call is hipGraph-capturable;
+ *   - all buffers (outputs, workspaces) are owned by the caller.
+ * dtype codes: MI_BF16 / MI_FP16 for activations and KV; FP8 is OCP e4m3fn (gfx950).
+ */
+#ifndef MI_HOTPATH_H
+#define MI_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
+enum {
+  MI_OK = 0,
+  MI_ERR_INVALID = -1,     /* bad argument (null pointer, bad size/stride/alignment) */
+  MI_ERR_UNSUPPORTED = -2, /* shape / dtype combination has no kernel */
+  MI_ERR_LAUNCH = -3       /* hipLaunch reported an error */
+};
+/* scale granularity for mi_fp8_gemm */
+enum { MI_SCALE_TENSOR = 0, MI_SCALE_ROW = 1 /* per token (A) / per channel (B) */ };
+/* weight packing for mi_w4a16_gemm */
+enum { MI_W4_AWQ = 0, MI_W4_GPTQ = 1 };
+
+int mi_abi_version(void);
+const char* mi_last_error(void);
+/* number of compute units of the current device (used by split heuristics) */
+int mi_device_cu_count(void);
+
+/* ---------------------------------------------------------------- integer path */
+
+/* kv_indptr[0]=0, kv_indptr[i+1]=sum_{j<=i} lens[j]  (int32 out; lens int32 or int64).
+ * replaces: torch.cumsum at triton_backend.py:173-174,303-306. */
+int mi_kv_indptr(const void* lens, int lens_is_i64, int32_t* kv_indptr, int64_t batch, void* stream);
+
+/* kv_indices[kv_indptr[b] + j] = req_to_token[req_pool_indices[b]*stride + start_b + j], j < lens[b]
+ * replaces: create_flashinfer_kv_indices_triton, layers/attention/utils.py:5-41 (bit-exact). */
+int mi_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                  const int64_t* req_pool_indices, const void* lens, int lens_is_i64,
+                  const int32_t* kv_indptr, const int32_t* kv_start_idx /* nullable */,
+                  int32_t* kv_indices, int64_t batch, void* stream);
+
+/* k_cache[loc[t]] = k[t]; v_cache[loc[t]] = v[t]   (rows of Hkv*D / Hkv*Dv elements, same dtype)
+ * replaces: MHATokenToKVPool.set_kv_buffer index_put, mem_cache/memory_pool.py:454-455. */
+int mi_kv_write(void* k_cache, void* v_cache, const int64_t* loc, const void* k, const void* v,
+                int64_t tokens, int64_t row_elems_k, int64_t row_elems_v,
+                int64_t cache_stride_k, int64_t cache_stride_v, /* elements between slots   */
+                int64_t src_stride_k, int64_t src_stride_v,     /* elements between tokens  */
+                int dtype, void* stream);
+
+/* ------------------------------------------------------------------- attention */
+
+/* bytes of fp32 workspace mi_decode_attn needs for (batch, Hq, Dv, num_splits) */
+int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t v_head_dim,
+                                       int64_t num_splits);
+
+/* Split-KV token (decode) attention over a paged KV pool, one query token per request.
+ *   q [B,Hq,D] (stride_q_tok elements between tokens, heads contiguous D apart)
+ *   k_buf/v_buf [slots,Hkv,D] (stride_*_slot elements between slots, heads D apart)
+ *   o [B,Hq,D] ; kv_indptr int32 [B+1] ; kv_indices int32 [kv_indptr[B]]
+ *   o[b,h] = softmax_j(sm_scale * q[b,h].k_buf[kv_indices[kv_indptr[b]+j], h/group]) . v_buf[...]
+ *   logit_cap > 0 applies cap*tanh(x/cap) to the scaled logits.
+ *   num_splits >= 1; workspace needed when num_splits > 1.
+ * replaces: decode_attention_fwd (stage1 + stage2), triton_ops/decode_attention.py:677-728;
+ * oracle: TorchNativeAttnBackend._run_sdpa_forward_decode, torch_native_backend.py:112-180. */
+int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
+                   const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
+                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                   int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_k_slot,
+                   int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
+                   int dtype, void* stream);
+
+/* Ragged extend (prefill-with-prefix) attention.
+ *   q_ext [E,Hq,D], k_ext/v_ext [E,Hkv,D] : the new tokens, request i owns rows
+ *   qo_indptr[i]..qo_indptr[i+1]; its cached prefix is kv_indices[kv_indptr[i]..kv_indptr[i+1])
+ *   into k_buf/v_buf.  Row j of request i attends the whole prefix plus new tokens 0..j
+ *   (causal) or all new tokens (non-causal).  sliding_window > 0 additionally requires
+ *   q_pos <= k_pos + sliding_window.
+ * replaces: extend_attention_fwd, triton_ops/extend_attention.py:306-438;
+ * oracle: TorchNativeAttnBackend._run_sdpa_forward_extend, torch_native_backend.py:27-110. */
+int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                   const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                   const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
+                   int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                   int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                   int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                   int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                   int64_t sliding_window, int dtype, void* stream);
+
+/* out = (a*e^{la} + b*e^{lb}) / (e^{la}+e^{lb}); out_lse = log(e^{la}+e^{lb})  (lse fp32, may be null)
+ *   a,b,out [n,h,d] contiguous; lse [n,h].
+ * replaces: merge_state_v2, sgl-kernel/csrc/attention/merge_attn_states.cu:31-106,182-204. */
+int mi_merge_state(const void* o_a, const float* lse_a, const void* o_b, const float* lse_b,
+                   void* out, float* out_lse, int64_t n, int64_t h, int64_t d, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------- FP8 (OCP e4m3fn) */
+
+/* Per-tensor quant: is_static ? scale given : scale[0] = absmax(x)/448 (written).
+ *   q = sat(x * (1/scale)) -> fp8.  x [M,K] row stride ldx elements, q contiguous [M,K].
+ *   In dynamic mode the call itself resets `scale` on the stream before reducing into it.
+ * replaces: sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:96-123
+ * (and vllm ops.scaled_fp8_quant per-tensor as called at fp8_utils.py:669-674). */
+int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int64_t M, int64_t K,
+                            int64_t ldx, int is_static, int dtype, void* stream);
+
+/* Per-token quant: scales[m] = absmax(x[m,:])/448.
+ * replaces: sgl_per_token_quant_fp8, sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:78-106. */
+int mi_fp8_quant_per_token(const void* x, void* q, float* scales, int64_t M, int64_t K,
+                           int64_t ldx, int dtype, void* stream);
+
+/* out[M,N] = (A[M,K] . B[K,N]) * sa * sb (+ bias) -> out_dtype, fp32 accumulate.
+ *   a   fp8 [M,K] row-major (lda), b_nk fp8 stored [N,K] row-major (ldb) == the column-major
+ *   [K,N] view the reference passes (fp8.py:364,406 `weight.t()`).
+ *   scale_a: 1 value (MI_SCALE_TENSOR) or M values (MI_SCALE_ROW); scale_b: 1 or N values.
+ * replaces: torch._scaled_mm at fp8_utils.py:715-723 / fallback :479-507, and
+ * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146. */
+int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                const void* bias /* nullable, out_dtype */, void* out, int64_t M, int64_t N,
+                int64_t K, int64_t lda, int64_t ldb, int64_t ldo, int scale_a_mode,
+                int scale_b_mode, int out_dtype, void* stream);
+
+/* -------------------------------------------------------- int4 weight-only GEMM */
+
+/* out[M,N] = x[M,K] . dequant(W)[K,N] (+ bias), dequant fused in the main loop.
+ *   MI_W4_AWQ : qweight [K,N/8] i32 (nibble order 0,4,1,5,2,6,3,7 along N), qzeros [K/g,N/8],
+ *               scales [K/g,N]; W = (w - z) * s.
+ *   MI_W4_GPTQ: qweight [K/8,N] i32 (packed along K), qzeros [K/g,N/8] (sequential nibbles,
+ *               stored minus one), scales [K/g,N], g_idx [K] or null; W = (w - (z+1)) * s[g_idx].
+ * replaces: awq_dequantize + torch.matmul, quantization/awq.py:199-203 with
+ * sgl-kernel/csrc/gemm/awq_kernel.cu:126-221; GPTQ: vllm gptq_gemm (parity unpinned). */
+int mi_w4a16_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                  const int32_t* g_idx /* nullable */, const void* bias /* nullable */, void* out,
+                  int64_t M, int64_t N, int64_t K, int64_t group_size, int layout, int dtype,
+                  void* stream);
+
+/* W[K,N] = dequant(qweight) in `dtype` (unfused form, for tests and tools).
+ * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221. */
+int mi_w4_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                     const int32_t* g_idx, void* w_out, int64_t N, int64_t K, int64_t group_size,
+                     int layout, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_HOTPATH_H */

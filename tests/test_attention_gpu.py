@@ -1,0 +1,202 @@
+"""GPU parity: HIP decode / indices / kv-write / merge vs the oracle and the golden vectors.
+All calls go through the C ABI (iaas_sglang_amd.ops -> libmi_hotpath.so)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention as oa  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def ops():
+    from iaas_sglang_amd import ops as _ops
+    return _ops
+
+
+def _tol(dtype):
+    # |hip - oracle| <= atol + rtol*|oracle| : 2 ulp of the I/O dtype + 1e-3 absolute
+    return dict(atol=2e-3, rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -9)
+
+
+def _run_decode(c, num_splits):
+    o_ = ops()
+    q = c["q"].to(DEV)
+    kc, vc = c["k_cache"].to(DEV).clone(), c["v_cache"].to(DEV).clone()
+    r2t, rpi, sl = c["req_to_token"].to(DEV), c["req_pool_indices"].to(DEV), c["seq_lens"].to(DEV)
+    loc = c["out_cache_loc"].to(DEV)
+    o_.kv_write(kc, vc, loc, c["k_new"].to(DEV), c["v_new"].to(DEV))
+    indptr = o_.kv_indptr(sl)
+    idx = torch.empty(int(sl.sum()), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t, rpi, sl, indptr, idx)
+    B, Hq, D = q.shape
+    out = torch.empty_like(q)
+    ws = torch.empty(max(1, o_.decode_workspace_numel(B, Hq, D, num_splits)), dtype=torch.float32, device=DEV)
+    o_.decode_attention(q, kc, vc, out, indptr, idx, float(c["scaling"]), 0.0, num_splits, ws)
+    torch.cuda.synchronize()
+    return out.cpu(), kc.cpu(), vc.cpu(), indptr.cpu(), idx.cpu()
+
+
+DECODE = ["decode_gqa4_d128_bf16", "decode_gqa8_d128_bf16", "decode_mha_d128_fp16",
+          "decode_mha_d64_fp16", "decode_gqa4_d128_bf16_shifted"]
+
+
+@pytest.mark.parametrize("name", DECODE)
+@pytest.mark.parametrize("num_splits", [1, 3, 8])
+def test_decode_matches_reference_golden(golden_attention, name, num_splits):
+    c = golden_attention[name]
+    out, kc, vc, indptr, idx = _run_decode(c, num_splits)
+    # integer path bit-exact
+    ip_ref, idx_ref = oa.kv_indices(c["req_to_token"], c["req_pool_indices"], c["seq_lens"])
+    assert torch.equal(indptr, ip_ref) and torch.equal(idx, idx_ref)
+    # pool contents after the write: bit-exact, every other slot untouched
+    k_exp, v_exp = c["k_cache"].clone(), c["v_cache"].clone()
+    k_exp[c["out_cache_loc"]] = c["k_new"]
+    v_exp[c["out_cache_loc"]] = c["v_new"]
+    assert torch.equal(kc, k_exp) and torch.equal(vc, v_exp)
+    # values: vs the reference's own bf16/fp16 output and vs exact fp32 math
+    torch.testing.assert_close(out.float(), c["o"].float(), atol=2e-2, rtol=2e-2)
+    o32 = oa.decode_fp32(c["q"], k_exp, v_exp, c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                         scaling=float(c["scaling"]))
+    torch.testing.assert_close(out.float(), o32, **_tol(out.dtype))
+
+
+def _synthetic(B, Hq, Hkv, D, lens, dtype, seed=0, scattered=True):
+    g = torch.Generator().manual_seed(seed)
+    total = int(sum(lens))
+    slots = total + 1
+    k = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    perm = (torch.randperm(total, generator=g) + 1) if scattered else (torch.arange(total) + 1)
+    ctx = max(lens) + 3
+    r2t = torch.zeros(B + 2, ctx, dtype=torch.int32)
+    rpi = torch.randperm(B + 2, generator=g)[:B]
+    off = 0
+    for i, L in enumerate(lens):
+        r2t[rpi[i], :L] = perm[off:off + L].to(torch.int32)
+        off += L
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    return q, k, v, r2t, rpi.to(torch.int64), torch.tensor(lens, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (8, 8, 128, torch.float16),
+                                            (12, 12, 64, torch.float16), (14, 2, 128, torch.bfloat16)])
+def test_decode_ragged_vs_oracle(Hq, Hkv, D, dtype):
+    lens = [1, 2, 15, 16, 17, 31, 32, 33, 100, 511, 512, 700]
+    q, k, v, r2t, rpi, sl = _synthetic(len(lens), Hq, Hkv, D, lens, dtype, seed=1)
+    o_ = ops()
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    indptr = o_.kv_indptr(sl.to(DEV))
+    idx = torch.empty(int(sl.sum()), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t.to(DEV), rpi.to(DEV), sl.to(DEV), indptr, idx)
+    ref = oa.decode_fp32(q, k, v, r2t, rpi, sl, scaling=1.0 / math.sqrt(D))
+    for ns in (1, 4, 16):
+        out = torch.empty_like(qd)
+        ws = torch.empty(max(1, o_.decode_workspace_numel(len(lens), Hq, D, ns)), dtype=torch.float32, device=DEV)
+        o_.decode_attention(qd, kd, vd, out, indptr, idx, 1.0 / math.sqrt(D), 0.0, ns, ws)
+        torch.testing.assert_close(out.cpu().float(), ref, **_tol(dtype))
+
+
+def test_decode_logit_cap_and_spiked_max():
+    # a spiked key forces the deferred-rescale branch late in the sequence; logit cap as in Triton
+    D, Hq, Hkv = 128, 8, 2
+    lens = [300, 90]
+    q, k, v, r2t, rpi, sl = _synthetic(2, Hq, Hkv, D, lens, torch.bfloat16, seed=4)
+    k[r2t[rpi[0], 250].item()] = (q[0, 0] * 3).to(k.dtype)  # huge logit for head 0 at token 250
+    o_ = ops()
+    indptr = o_.kv_indptr(sl.to(DEV))
+    idx = torch.empty(int(sl.sum()), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t.to(DEV), rpi.to(DEV), sl.to(DEV), indptr, idx)
+    for cap in (0.0, 30.0):
+        ref = oa.decode_fp32(q, k, v, r2t, rpi, sl, scaling=1.0 / math.sqrt(D), logit_cap=cap)
+        for ns in (1, 2):
+            out = torch.empty(2, Hq, D, dtype=torch.bfloat16, device=DEV)
+            ws = torch.empty(max(1, o_.decode_workspace_numel(2, Hq, D, ns)), dtype=torch.float32, device=DEV)
+            o_.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), out, indptr, idx, 1.0 / math.sqrt(D), cap, ns, ws)
+            torch.testing.assert_close(out.cpu().float(), ref, **_tol(torch.bfloat16))
+
+
+def test_kv_indices_like_reference_test():
+    # test/srt/test_create_kvindices.py:18-71: batch in {1, 37, 1786}, 4096 x 4096 table
+    o_ = ops()
+    max_batch = ctx = 4096
+    r2t = torch.arange(max_batch * ctx, dtype=torch.int32, device=DEV).reshape(max_batch, ctx)
+    g = torch.Generator().manual_seed(0)
+    for batch in (1, 37, 1786):
+        rpi = torch.randperm(max_batch, generator=g)[:batch].to(torch.int64)
+        lens = torch.randperm(ctx, generator=g)[:batch].to(torch.int32)
+        for lens_t in (lens, lens.to(torch.int64)):
+            indptr = o_.kv_indptr(lens_t.to(DEV))
+            out = torch.empty(int(lens.sum()), dtype=torch.int32, device=DEV)
+            o_.kv_indices(r2t, rpi.to(DEV), lens_t.to(DEV), indptr, out)
+            ip_ref, ref = oa.kv_indices(r2t.cpu(), rpi, lens)
+            assert torch.equal(indptr.cpu(), ip_ref)
+            assert torch.equal(out.cpu(), ref)
+    # kv_start_idx variant (sliding-window builder, attention/utils.py:22-26)
+    rpi = torch.tensor([5, 9], dtype=torch.int64)
+    lens = torch.tensor([100, 7], dtype=torch.int32)
+    start = torch.tensor([11, 0], dtype=torch.int32)
+    indptr = o_.kv_indptr(lens.to(DEV))
+    out = torch.empty(107, dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t, rpi.to(DEV), lens.to(DEV), indptr, out, start.to(DEV))
+    _, ref = oa.kv_indices(r2t.cpu(), rpi, lens, start)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_merge_state_vs_oracle():
+    o_ = ops()
+    g = torch.Generator().manual_seed(2)
+    for dtype in (torch.bfloat16, torch.float16):
+        a = torch.randn(37, 6, 128, generator=g).to(dtype)
+        b = torch.randn(37, 6, 128, generator=g).to(dtype)
+        la = torch.randn(37, 6, generator=g) * 3
+        lb = torch.randn(37, 6, generator=g) * 3
+        lb[3, 2] = float("inf")
+        la[5, 1] = float("-inf")
+        out, lse = o_.merge_state(a.to(DEV), la.to(DEV), b.to(DEV), lb.to(DEV))
+        ro, rl = oa.merge_state(a, la, b, lb)
+        torch.testing.assert_close(out.cpu().float(), ro.float(), atol=1e-3, rtol=2 ** -7)
+        torch.testing.assert_close(lse.cpu(), rl, atol=1e-5, rtol=1e-5)
+
+
+def test_decode_full_size_properties():
+    """BASELINE config (B=128, S=2048, Hq=32, Hkv=8, D=128) -- too big for the CPU oracle in
+    seconds, so check size-independent properties: split-count invariance, permutation
+    invariance of the slot assignment, and a constant-V identity (softmax weights sum to 1)."""
+    o_ = ops()
+    B, S, Hq, Hkv, D = 128, 2048, 32, 8, 128
+    g = torch.Generator(device=DEV).manual_seed(0)
+    slots = B * S + 1
+    k = torch.randn(slots, Hkv, D, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    v = torch.randn(slots, Hkv, D, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn(B, Hq, D, device=DEV, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    perm = torch.randperm(B * S, device=DEV, generator=g).to(torch.int32) + 1
+    sl = torch.full((B,), S, dtype=torch.int64, device=DEV)
+    indptr = o_.kv_indptr(sl)
+    scale = 1.0 / math.sqrt(D)
+
+    def run(idx, vbuf, ns):
+        out = torch.empty_like(q)
+        ws = torch.empty(max(1, o_.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=DEV)
+        o_.decode_attention(q, k, vbuf, out, indptr, idx, scale, 0.0, ns, ws)
+        return out.float()
+
+    base = run(perm, v, 1)
+    for ns in (2, 4, 8):
+        torch.testing.assert_close(run(perm, v, ns), base, atol=4e-3, rtol=2 ** -7)
+    # attention is invariant to the ORDER of a request's kv_indices
+    shuffled = perm.view(B, S)[:, torch.randperm(S, device=DEV, generator=g)].contiguous().view(-1)
+    torch.testing.assert_close(run(shuffled, v, 4), base, atol=4e-3, rtol=2 ** -7)
+    # constant V => output equals that constant (weights sum to one)
+    vconst = torch.full_like(v, 0.5)
+    out = run(perm, vconst, 4)
+    torch.testing.assert_close(out, torch.full_like(out, 0.5), atol=1e-3, rtol=0)
+    # spot-check 3 requests against the fp32 oracle
+    sel = [0, 63, 127]
+    r2t = perm.view(B, S).cpu()
+    ref = oa.decode_fp32(q[sel].cpu(), k.cpu(), v.cpu(), r2t[sel], torch.arange(3), torch.full((3,), S),
+                         scaling=scale)
+    torch.testing.assert_close(base[sel].cpu(), ref, **_tol(torch.bfloat16))
