@@ -270,8 +270,10 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
   const bool active = lane * EPL < D;
   for (int s = 0; s < nsplit; ++s) {
+    const float ls = ml[2 * s + 1];
+    if (!(ls > 0.f)) continue;  // empty split: its ws_o slice was never written
     const float w = fast_exp2(ml[2 * s] - M);
-    L += ml[2 * s + 1] * w;
+    L += ls * w;
     if (active) {
       const float* po = ws_o + (bh * nsplit + s) * D + lane * EPL;
 #pragma unroll

@@ -194,24 +194,46 @@ def fp8_gemm(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b
 
 
 # -------------------------------------------------------------------------- int4
-def w4a16_gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
-               group_size: int, layout: int, g_idx: Optional[torch.Tensor] = None,
-               bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    assert x.dim() == 2 and x.is_contiguous()
-    M, K = x.shape
+def w4_repack(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, group_size: int,
+              layout: int, g_idx: Optional[torch.Tensor] = None):
+    """Checkpoint-layout int4 weights -> (qw_native, zs_native, perm) for w4a16_gemm.
+    For GPTQ act-order (g_idx not sorted) perm = argsort(g_idx) (host-side, once at load)."""
     N = scales.shape[1]
-    assert qweight.dtype == torch.int32 and qzeros.dtype == torch.int32 and scales.dtype == x.dtype
+    K = qweight.shape[0] if layout == MI_W4_AWQ else qweight.shape[0] * 8
+    assert qweight.dtype == torch.int32 and qzeros.dtype == torch.int32
     assert qweight.is_contiguous() and qzeros.is_contiguous() and scales.is_contiguous()
+    perm = None
+    if g_idx is not None:
+        gi = g_idx.to(torch.int64)
+        if not bool((gi[1:] >= gi[:-1]).all()):
+            perm = torch.argsort(gi, stable=True).to(torch.int32).contiguous()
+    qw = torch.empty(N * K // 8, dtype=torch.int32, device=qweight.device)
+    zs = torch.empty(K // group_size, N, dtype=torch.int32, device=qweight.device)
+    check(lib.mi_w4_repack(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(perm), _ptr(qw), _ptr(zs), N, K,
+                           int(group_size), int(layout), _dt(scales), _stream()), "mi_w4_repack")
+    return qw, zs, perm
+
+
+def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, group_size: int,
+               perm: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
-    check(lib.mi_w4a16_gemm(_ptr(x), _ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(bias),
-                            _ptr(out), M, N, K, int(group_size), int(layout), _dt(x), _stream()), "mi_w4a16_gemm")
+    if bias is not None:
+        assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    check(lib.mi_w4a16_gemm(_ptr(x), _ptr(qw), _ptr(zs), _ptr(perm), _ptr(bias), _ptr(out), M, N, K,
+                            int(group_size), x.stride(0), out.stride(0), _dt(x), _stream()), "mi_w4a16_gemm")
     return out
 
 
 def w4_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, group_size: int,
                   layout: int, g_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense [K,N] weight from the checkpoint layout (the reference's `awq_dequantize` op)."""
     N = scales.shape[1]
     K = qweight.shape[0] if layout == MI_W4_AWQ else qweight.shape[0] * 8
+    if g_idx is not None:
+        g_idx = g_idx.to(torch.int32).contiguous()
     out = torch.empty(K, N, dtype=scales.dtype, device=scales.device)
     check(lib.mi_w4_dequantize(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(out), N, K,
                                int(group_size), int(layout), _dt(scales), _stream()), "mi_w4_dequantize")

@@ -138,23 +138,35 @@ int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a, const flo
 
 /* -------------------------------------------------------- int4 weight-only GEMM */
 
-/* out[M,N] = x[M,K] . dequant(W)[K,N] (+ bias), dequant fused in the main loop.
- *   MI_W4_AWQ : qweight [K,N/8] i32 (nibble order 0,4,1,5,2,6,3,7 along N), qzeros [K/g,N/8],
- *               scales [K/g,N]; W = (w - z) * s.
+/* One-time weight repack (called from process_weights_after_loading) of a 4-bit checkpoint into
+ * the MFMA-native layout consumed by mi_w4a16_gemm:
+ *   MI_W4_AWQ : qweight [K,N/8] i32 (logical column 8c+j is nibble {0,4,1,5,2,6,3,7}[j] of word
+ *               c), qzeros [K/g,N/8] packed the same way, scales [K/g,N]; W = (w - z) * s
  *   MI_W4_GPTQ: qweight [K/8,N] i32 (packed along K), qzeros [K/g,N/8] (sequential nibbles,
- *               stored minus one), scales [K/g,N], g_idx [K] or null; W = (w - (z+1)) * s[g_idx].
+ *               stored minus one), scales [K/g,N]; W = (w - (z+1)) * s; `perm` (i32 [K], nullable) = argsort(g_idx)
+ *               for act-order checkpoints: native row k' holds checkpoint row perm[k'].
+ *   out: qw_native u32 [N/16][K/128][64][4] (N*K/2 bytes), zs_native u32 [K/g][N].
+ * replaces: the weight layout prepared in AWQLinearMethod.process_weights_after_loading,
+ * quantization/awq.py:183-186 (and vllm's gptq shuffle). */
+int mi_w4_repack(const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                 const int32_t* perm /* nullable */, void* qw_native, void* zs_native, int64_t N,
+                 int64_t K, int64_t group_size, int layout, int dtype, void* stream);
+
+/* out[M,N] = x[M,K] . dequant(W)[K,N] (+ bias); dequant W = (w - z) * s is fused into the MFMA
+ * main loop and is bit-identical to the reference's dequantised fp16/bf16 weight.
+ *   x [M,K] (ldx), qw_native/zs_native from mi_w4_repack, perm as given to mi_w4_repack.
  * replaces: awq_dequantize + torch.matmul, quantization/awq.py:199-203 with
  * sgl-kernel/csrc/gemm/awq_kernel.cu:126-221; GPTQ: vllm gptq_gemm (parity unpinned). */
-int mi_w4a16_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
-                  const int32_t* g_idx /* nullable */, const void* bias /* nullable */, void* out,
-                  int64_t M, int64_t N, int64_t K, int64_t group_size, int layout, int dtype,
-                  void* stream);
+int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native,
+                  const int32_t* perm /* nullable */, const void* bias /* nullable */, void* out,
+                  int64_t M, int64_t N, int64_t K, int64_t group_size, int64_t ldx, int64_t ldo,
+                  int dtype, void* stream);
 
-/* W[K,N] = dequant(qweight) in `dtype` (unfused form, for tests and tools).
+/* W[K,N] = dequant(checkpoint-layout qweight) in `dtype` (unfused form, for tests and tools).
  * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221. */
 int mi_w4_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* scales,
-                     const int32_t* g_idx, void* w_out, int64_t N, int64_t K, int64_t group_size,
-                     int layout, int dtype, void* stream);
+                     const int32_t* g_idx /* nullable */, void* w_out, int64_t N, int64_t K,
+                     int64_t group_size, int layout, int dtype, void* stream);
 
 #ifdef __cplusplus
 }
