@@ -200,3 +200,137 @@ def test_decode_full_size_properties():
     ref = oa.decode_fp32(q[sel].cpu(), k.cpu(), v.cpu(), r2t[sel], torch.arange(3), torch.full((3,), S),
                          scaling=scale)
     torch.testing.assert_close(base[sel].cpu(), ref, **_tol(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------ extend
+EXTEND = ["extend_gqa4_d128_bf16_noprefix", "extend_gqa4_d128_bf16_prefix",
+          "extend_mha_d64_fp16_prefix", "extend_gqa4_d128_bf16_noncausal"]
+
+
+def _run_extend(c, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal, logit_cap=0.0, window=-1):
+    """The backend's extend sequence through the C ABI: KV write, prefix kv_indices, kernel."""
+    o_ = ops()
+    d = lambda t: t.to(DEV)
+    kc, vc = d(kc).clone(), d(vc).clone()
+    B = len(pre)
+    lens = pre + ext
+    loc = torch.cat([r2t[rpi[i], int(pre[i]):int(lens[i])] for i in range(B)]).to(torch.int64)
+    o_.kv_write(kc, vc, d(loc), d(k_new), d(v_new))
+    pre_d, ext_d = d(pre.to(torch.int32)), d(ext.to(torch.int32))
+    kv_indptr = o_.kv_indptr(pre_d)
+    qo_indptr = o_.kv_indptr(ext_d)
+    idx = torch.empty(max(1, int(pre.sum())), dtype=torch.int32, device=DEV)
+    o_.kv_indices(d(r2t), d(rpi), pre_d, kv_indptr, idx)
+    out = torch.empty_like(d(q))
+    o_.extend_attention(d(q), d(k_new), d(v_new), out, kc, vc, qo_indptr, kv_indptr, idx, int(ext.max()),
+                        scaling, logit_cap, causal, window)
+    torch.cuda.synchronize()
+    return out.cpu(), kc.cpu(), vc.cpu()
+
+
+@pytest.mark.parametrize("name", EXTEND)
+def test_extend_matches_reference_golden(golden_attention, name):
+    c = golden_attention[name]
+    pre, ext = c["extend_prefix_lens"].to(torch.int64), c["extend_seq_lens"].to(torch.int64)
+    out, kc, vc = _run_extend(c, c["q"], c["k_new"], c["v_new"], c["k_cache"], c["v_cache"], c["req_to_token"],
+                              c["req_pool_indices"], pre, ext, float(c["scaling"]), bool(c["causal"]))
+    k_exp, v_exp = c["k_cache"].clone(), c["v_cache"].clone()
+    k_exp[c["out_cache_loc"]] = c["k_new"]
+    v_exp[c["out_cache_loc"]] = c["v_new"]
+    assert torch.equal(kc, k_exp) and torch.equal(vc, v_exp)
+    torch.testing.assert_close(out.float(), c["o"].float(), atol=2e-2, rtol=2e-2)
+    o32 = oa.extend_fp32(c["q"], k_exp, v_exp, c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                         c["extend_prefix_lens"], c["extend_seq_lens"], scaling=float(c["scaling"]),
+                         causal=bool(c["causal"]))
+    # P is rounded to the I/O dtype before the PV MFMA (as the Triton kernel does, extend_attention.py:205)
+    torch.testing.assert_close(out.float(), o32, atol=4e-3, rtol=2 ** -6 if out.dtype == torch.bfloat16 else 2 ** -8)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (4, 4, 128, torch.float16),
+                                            (12, 12, 64, torch.float16), (8, 4, 128, torch.bfloat16),
+                                            (8, 1, 128, torch.bfloat16), (6, 2, 64, torch.bfloat16)])
+def test_extend_ragged_vs_oracle(Hq, Hkv, D, dtype):
+    # MIXED-style batch: long prefill chunks next to 1-token extends with long prefixes (SURVEY App. B)
+    pre = torch.tensor([0, 0, 64, 300, 33, 1, 129, 0])
+    ext = torch.tensor([1, 130, 17, 1, 64, 200, 31, 65])
+    lens = (pre + ext).tolist()
+    g = torch.Generator().manual_seed(7)
+    slots = sum(lens) + 1
+    kc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    vc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    perm = torch.randperm(slots - 1, generator=g) + 1
+    B = len(lens)
+    r2t = torch.zeros(B + 1, max(lens) + 2, dtype=torch.int32)
+    rpi = torch.randperm(B + 1, generator=g)[:B].to(torch.int64)
+    off = 0
+    for i, L in enumerate(lens):
+        r2t[rpi[i], :L] = perm[off:off + L].to(torch.int32)
+        off += L
+    r2t[rpi[4], :33] = r2t[rpi[3], :33]   # shared radix prefix
+    E = int(ext.sum())
+    q = torch.randn(E, Hq, D, generator=g).to(dtype)
+    k_new = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    v_new = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    scaling = D ** -0.5
+    for causal, cap, window in [(True, 0.0, -1), (False, 0.0, -1), (True, 50.0, -1), (True, 0.0, 40)]:
+        out, kca, vca = _run_extend(None, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal, cap, window)
+        ref = oa.extend_fp32(q, kca, vca, r2t, rpi, torch.tensor(lens), pre, ext, scaling=scaling, causal=causal,
+                             logit_cap=cap, sliding_window=window)
+        torch.testing.assert_close(out.float(), ref, atol=4e-3, rtol=2 ** -6 if dtype == torch.bfloat16 else 2 ** -8)
+
+
+def test_extend_reference_test_shape():
+    # shape family of test/srt/test_triton_attention_kernels.py:44-181 (B=19, Hq=12, Hkv=4, D=128), reduced N_CTX
+    g = torch.Generator().manual_seed(0)
+    B, Hq, Hkv, D, dtype = 19, 12, 4, 128, torch.bfloat16
+    pre = torch.randint(1, 300, (B,), generator=g)
+    ext = torch.randint(1, 300, (B,), generator=g)
+    lens = (pre + ext).tolist()
+    slots = sum(lens) + 1
+    kc = (torch.randn(slots, Hkv, D, generator=g) * 0.2 + 0.1).to(dtype)
+    vc = (torch.randn(slots, Hkv, D, generator=g) * 0.2 + 0.1).to(dtype)
+    r2t = torch.zeros(B, max(lens), dtype=torch.int32)
+    off = 1
+    for i, L in enumerate(lens):   # contiguous slots, like the reference test's b_start_loc layout
+        r2t[i, :L] = torch.arange(off, off + L, dtype=torch.int32)
+        off += L
+    rpi = torch.arange(B, dtype=torch.int64)
+    E = int(ext.sum())
+    q = (torch.randn(E, Hq, D, generator=g) * 0.2 + 0.1).to(dtype)
+    k_new = (torch.randn(E, Hkv, D, generator=g) * 0.2 + 0.1).to(dtype)
+    v_new = (torch.randn(E, Hkv, D, generator=g) * 0.2 + 0.1).to(dtype)
+    out, kca, vca = _run_extend(None, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, D ** -0.5, True)
+    ref = oa.extend_fp32(q, kca, vca, r2t, rpi, torch.tensor(lens), pre, ext, scaling=D ** -0.5)
+    # the reference's own tolerance for this test is rtol 1e-2 (:171-181)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=2e-3)
+
+
+def test_extend_len1_equals_decode():
+    # an extend of one token over a prefix must equal token (decode) attention over prefix+1 keys
+    o_ = ops()
+    g = torch.Generator().manual_seed(3)
+    B, Hq, Hkv, D, dtype = 5, 32, 8, 128, torch.bfloat16
+    pre = torch.tensor([7, 100, 513, 64, 1])
+    ext = torch.ones(B, dtype=torch.int64)
+    lens = (pre + ext).tolist()
+    slots = sum(lens) + 1
+    kc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    vc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    perm = torch.randperm(slots - 1, generator=g) + 1
+    r2t = torch.zeros(B, max(lens), dtype=torch.int32)
+    off = 0
+    for i, L in enumerate(lens):
+        r2t[i, :L] = perm[off:off + L].to(torch.int32)
+        off += L
+    rpi = torch.arange(B, dtype=torch.int64)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    k_new = torch.randn(B, Hkv, D, generator=g).to(dtype)
+    v_new = torch.randn(B, Hkv, D, generator=g).to(dtype)
+    out_e, kca, vca = _run_extend(None, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, D ** -0.5, True)
+    sl = torch.tensor(lens, dtype=torch.int64).to(DEV)
+    indptr = o_.kv_indptr(sl)
+    idx = torch.empty(sum(lens), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t.to(DEV), rpi.to(DEV), sl, indptr, idx)
+    out_d = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+    o_.decode_attention(q.to(DEV), kca.to(DEV), vca.to(DEV), out_d, indptr, idx, D ** -0.5)
+    torch.testing.assert_close(out_e.float(), out_d.cpu().float(), atol=4e-3, rtol=2 ** -6)
