@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of the hot path at BASELINE.json's configuration --
+Llama-3-8B, per-tensor FP8 linears, TP = --gpus, batch 128, KV length 2048, bf16 paged KV
+(page_size 1, slots scattered over the pool), synthetic data, dummy weights.
+
+One "step" = one decode step of the whole layer stack through the plugin surfaces
+(MiAttnBackend.init_forward_metadata + forward, Fp8LinearMethod.apply, plus the glue kernels and
+the bf16 lm_head), captured once in a hipGraph and replayed.  Inputs (weights, KV pool,
+req_to_token) are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W          (TP=N over RCCL)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
+    ap.add_argument("--contiguous", action="store_true", help="contiguous KV slots instead of scattered")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
+    ap.add_argument("--kernel-reps", type=int, default=3, help="passes over all layers for the roofline timing")
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n:
+        if world == 1 and n > 1:
+            raise SystemExit(f"--gpus {n} needs torch.distributed.run with --nproc-per-node {n}")
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = torch.distributed.group.WORLD
+    return world, rank, local, group
+
+
+def barrier_sync(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def attention_bytes(B, S, Hkv, D, Hq, esize=2):
+    """Algorithmic bytes of ONE decode-attention launch: K+V rows once, q, o, kv_indices."""
+    return 2 * B * S * Hkv * D * esize + 2 * B * Hq * D * esize + 4 * B * S
+
+
+def time_attention_kernel(stack, runner, backend, fb, reps):
+    """Average duration of one decode-attention launch, HIP events on the launch stream, cycling
+    through every layer's pool so nothing is served from the 256 MB Infinity Cache."""
+    from iaas_sglang_amd import ops
+    s = stack.shape
+    B = fb.batch_size
+    q = torch.randn(B, stack.Hq, s.head_dim, device=runner.device, dtype=torch.float32).to(stack.dtype)
+    o = torch.empty_like(q)
+    md = backend.forward_metadata
+    pool = runner.token_to_kv_pool
+
+    def one_pass():
+        for li in range(s.layers):
+            ops.decode_attention(q, pool.get_key_buffer(li), pool.get_value_buffer(li), o, md.kv_indptr,
+                                 md.kv_indices, s.head_dim ** -0.5, 0.0, md.num_kv_splits, md.workspace)
+
+    one_pass()
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        one_pass()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (reps * s.layers)
+
+
+def cpu_baseline(shape, B, S, timed_layers=2):
+    """The reference's torch-native arithmetic (our CPU restatement, oracle/) for ONE decoder layer at
+    the full batch/sequence size, timed on the host cores; extrapolated to `shape.layers` + lm_head."""
+    from oracle import attention as oa
+    from oracle import elementwise as oe
+    from oracle import quant as oq
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    D, Hq, Hkv, H, I = shape.head_dim, shape.num_heads, shape.num_kv_heads, shape.hidden, shape.intermediate
+    dt = torch.bfloat16
+
+    def w(n, k):
+        t = (torch.rand(n, k, generator=g) * 2e-3 - 1e-3).to(dt)
+        q, inv = oq.input_to_float8(t)
+        return q.t(), inv.reshape(1)
+
+    qkv_w, qkv_s = w((Hq + 2 * Hkv) * D, H)
+    o_w, o_s = w(H, Hq * D)
+    gu_w, gu_s = w(2 * I, H)
+    dn_w, dn_s = w(H, I)
+    norm_w = torch.ones(H, dtype=dt)
+    slots = B * S + 1
+    kc = torch.randn(slots, Hkv, D, generator=g, dtype=torch.float32).to(dt)
+    vc = torch.randn(slots, Hkv, D, generator=g, dtype=torch.float32).to(dt)
+    r2t = (torch.randperm(B * S, generator=g) + 1).to(torch.int32).view(B, S)
+    rpi = torch.arange(B)
+    sl = torch.full((B,), S, dtype=torch.int64)
+    loc = r2t[:, S - 1].to(torch.int64)
+    pos = sl - 1
+    cache = oe.rope_cos_sin_cache(D, S + 8, shape.rope_theta)
+    x0 = torch.randn(B, H, generator=g).to(dt)
+
+    def layer(hidden, residual):
+        x, residual = oe.rmsnorm(hidden, norm_w, shape.rms_eps, residual)
+        qkv = oq.fp8_linear(x, qkv_w, qkv_s)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        q, k = oe.rope_neox(pos, q.contiguous(), k.contiguous(), cache, D)
+        a = oa.forward_decode(q, k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D), kc, vc, r2t, rpi, sl, loc, Hq, Hkv,
+                              D ** -0.5)
+        hidden = oq.fp8_linear(a, o_w, o_s)
+        x, residual = oe.rmsnorm(hidden, norm_w, shape.rms_eps, residual)
+        hidden = oq.fp8_linear(oe.silu_and_mul(oq.fp8_linear(x, gu_w, gu_s)), dn_w, dn_s)
+        return hidden, residual
+
+    h, r = layer(x0, x0.clone())          # warm-up
+    times = []
+    for _ in range(timed_layers):
+        t0 = time.perf_counter()
+        h, r = layer(h, r)
+        times.append(time.perf_counter() - t0)
+    t_layer = sorted(times)[len(times) // 2]
+    lm = (torch.rand(8192, H, generator=g) * 2e-3 - 1e-3).to(dt)     # 1/15.66 of the vocab rows
+    t0 = time.perf_counter()
+    _ = h @ lm.t()
+    t_lm = (time.perf_counter() - t0) * (shape.vocab / 8192)
+    step = t_layer * shape.layers + t_lm
+    return {"value": round(B / step, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ (torch CPU restatement of the reference torch-native path): {timed_layers} timed "
+                      f"decoder layers at B={B}, S={S} (median {t_layer:.3f} s/layer) x {shape.layers} layers "
+                      f"+ lm_head extrapolated from 8192 of {shape.vocab} rows"}
+
+
+def main():
+    a = parse()
+    world, rank, local, group = dist_setup(a.gpus)
+    dev = torch.device("cuda", local)
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import Fp8Config
+    import dataclasses
+
+    shape = H.LLAMA3_8B
+    if a.layers:
+        shape = dataclasses.replace(shape, layers=a.layers)
+    tp, B, S, dtype = world, a.batch, a.seq, torch.bfloat16
+    if a.splits:
+        os.environ["MI_ATTN_MAX_KV_SPLITS"] = str(a.splits)
+
+    runner = H.make_runner(shape, max_reqs=B, ctx=S + 8, pool_tokens=B * S, dtype=dtype, device=dev, tp=tp,
+                           fill_kv=True, seed=rank, max_kv_splits=a.splits or 8)
+    backend = MiAttnBackend(runner)
+    if a.splits:
+        backend._choose_splits = lambda bs, tot: a.splits
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=False, activation_scheme="dynamic")
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=tp, rank=rank, group=group)
+    fb = H.make_decode_batch(runner, backend, B, S, dev, scattered=not a.contiguous, seed=0)
+    ids = torch.randint(0, shape.vocab, (B,), device=dev)
+    out_ids = torch.empty_like(ids)
+
+    def step():
+        hidden = torch.index_select(stack.embed, 0, ids)
+        backend.init_forward_metadata(fb)
+        logits = stack.forward(hidden, fb.positions, fb, backend)
+        torch.argmax(logits, dim=-1, out=out_ids)
+
+    step()                      # eager once: allocator warm-up, lazy inits
+    barrier_sync(world)
+    graph = None
+    if not a.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    for _ in range(a.warmup):
+        run()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier_sync(world)
+    elapsed = time.perf_counter() - t0
+    from iaas_sglang_amd.parallel import max_over_ranks
+    elapsed = max_over_ranks(elapsed, world, dev)
+    ms_per_step = elapsed / a.steps * 1e3
+    tokens_per_s = B / (ms_per_step * 1e-3)          # TP: one batch of B tokens per step for the whole job
+
+    # ---- roofline of the dominant kernel (decode attention), measured live with HIP events
+    Hq, Hkv, D = stack.Hq, stack.Hkv, shape.head_dim
+    t_attn = time_attention_kernel(stack, runner, backend, fb, a.kernel_reps)
+    abytes = attention_bytes(B, S, Hkv, D, Hq)
+    achieved = abytes / t_attn / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "decode_attn_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B and tj.get("seq") == S and tj.get("tp") == tp:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    step_bytes = (shape.layers * (abytes + (stack.q_size + 2 * stack.kv_size) * shape.hidden + stack.q_size * shape.hidden
+                                  + 3 * stack.inter * shape.hidden) + stack.vocab_shard * shape.hidden * 2)
+    result = {
+        "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)",
+        "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), bf16 KV/f32 softmax (attention)",
+        "data": "synthetic",
+        "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears (dynamic activation scale), "
+                               f"bf16 paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
+                               f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
+                   "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
+                   "kv_splits": backend.forward_metadata.num_kv_splits},
+        "step_hbm_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": {"kernel": "decode_attn_kernel (+ split merge)", "bound": "hbm", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(t_attn * 1e6, 2)},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(H.LLAMA3_8B, B, S)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,9 @@ SIGNATURES = {
     "mi_fp8_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _p]),
     "mi_w4_repack": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_rmsnorm": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
+    "mi_rope_neox": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_silu_and_mul": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_w4_dequantize": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
 }
 

@@ -1,0 +1,183 @@
+"""`MiAttnBackend`: the reference's AttentionBackend plugin surface on hand-written gfx950 HIP.
+
+Mirrors TritonAttnBackend's metadata protocol (python/sglang/srt/layers/attention/
+triton_backend.py:160-336, 338-627) and TorchNativeAttnBackend's numerics
+(torch_native_backend.py:182-267): KV write at out_cache_loc, then attention over the paged
+pool indexed through req_to_token.  No Triton, no torch math: every step is a C-ABI call
+(kv_indptr scan, kv_indices gather, kv_write scatter, decode / extend kernels).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._compat import AttentionBackend
+
+
+@dataclass
+class ForwardMetadata:
+    """Same role as triton_backend.py:23-37 (fields we do not need are dropped)."""
+    kv_indptr: torch.Tensor
+    kv_indices: torch.Tensor
+    qo_indptr: Optional[torch.Tensor]
+    max_extend_len: Optional[int]
+    num_kv_splits: int
+    workspace: Optional[torch.Tensor]
+
+
+class MiAttnBackend(AttentionBackend):
+    def __init__(self, model_runner, skip_prefill: bool = False):
+        super().__init__()
+        self.device = model_runner.device
+        self.req_to_token = model_runner.req_to_token_pool.req_to_token
+        max_bs = model_runner.req_to_token_pool.size
+        mc = model_runner.model_config
+        tp = getattr(model_runner, "tp_size", 1) or 1
+        self.num_head = mc.num_attention_heads // tp
+        self.num_kv_head = mc.get_num_kv_heads(tp) if hasattr(mc, "get_num_kv_heads") else mc.num_key_value_heads
+        self.max_context_len = mc.context_len
+        self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        sa = getattr(model_runner, "server_args", None)
+        # --triton-attention-num-kv-splits (server_args.py:210) is reused as the split cap
+        self.max_kv_splits = int(os.environ.get("MI_ATTN_MAX_KV_SPLITS",
+                                                getattr(sa, "triton_attention_num_kv_splits", 8) or 8))
+        if getattr(model_runner, "sliding_window_size", None):
+            raise NotImplementedError("MiAttnBackend: sliding-window models are not wired yet")
+        self.skip_prefill = skip_prefill
+        self.kv_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
+        self.qo_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
+        self.cu_count = max(ops.cu_count(), 1)
+        self.forward_metadata: Optional[ForwardMetadata] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ helpers
+    def _choose_splits(self, bs: int, seq_lens_sum: int) -> int:
+        """Split-KV count (replaces get_num_kv_splits_triton, triton_backend.py:875-924): enough
+        (request, kv-head, split) waves to fill every CU several times over, never splitting below
+        ~256 keys.  Any value gives the same math up to fp32 reassociation."""
+        waves = bs * self.num_kv_head
+        want = -(-self.cu_count * 16 // max(waves, 1))
+        avg = max(seq_lens_sum // max(bs, 1), 1)
+        return int(max(1, min(self.max_kv_splits, want, max(avg // 256, 1))))
+
+    def _workspace(self, bs: int, splits: int) -> Optional[torch.Tensor]:
+        n = ops.decode_workspace_numel(bs, self.num_head, self.v_head_dim, splits)
+        if n == 0:
+            return None
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    # ----------------------------------------------------------------- metadata
+    def init_forward_metadata(self, forward_batch):
+        bs = forward_batch.batch_size
+        mode = forward_batch.forward_mode
+        if getattr(forward_batch, "spec_info", None) is not None or mode.is_target_verify() or mode.is_draft_extend():
+            raise NotImplementedError("MiAttnBackend: speculative decoding modes are out of scope")
+        if mode.is_decode_or_idle():
+            kv_indptr = ops.kv_indptr(forward_batch.seq_lens, self.kv_indptr)
+            kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum), 1), dtype=torch.int32, device=self.device)
+            ops.kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
+                           kv_indices)
+            splits = self._choose_splits(bs, int(forward_batch.seq_lens_sum))
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, None, None, splits,
+                                                    self._workspace(bs, splits))
+        else:
+            # extend / mixed: kv_indices cover the cached PREFIX only (triton_backend.py:302-321); the
+            # host-side length lists avoid the reference's .item() syncs (:288,:320)
+            prefix_cpu = forward_batch.extend_prefix_lens_cpu
+            ext_cpu = forward_batch.extend_seq_lens_cpu
+            prefix_sum = int(sum(prefix_cpu)) if prefix_cpu is not None else int(forward_batch.extend_prefix_lens.sum())
+            max_ext = int(max(ext_cpu)) if ext_cpu is not None else int(forward_batch.extend_seq_lens.max())
+            kv_indptr = ops.kv_indptr(forward_batch.extend_prefix_lens, self.kv_indptr)
+            kv_indices = torch.empty(max(prefix_sum, 1), dtype=torch.int32, device=self.device)
+            ops.kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens,
+                           kv_indptr, kv_indices)
+            qo_indptr = ops.kv_indptr(forward_batch.extend_seq_lens, self.qo_indptr)
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, 1, None)
+
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
+        """Preallocate everything replay touches (triton_backend.py:338-388)."""
+        self.cuda_graph_kv_indices = (kv_indices_buf if kv_indices_buf is not None else
+                                      torch.zeros(max_num_tokens * self.max_context_len, dtype=torch.int32,
+                                                  device=self.device))
+        n = ops.decode_workspace_numel(max_num_tokens, self.num_head, self.v_head_dim, self.max_kv_splits)
+        self.cuda_graph_workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        self.cuda_graph_splits = {}
+
+    def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
+                                                 forward_mode, spec_info):
+        assert encoder_lens is None, "Not supported"
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for graph capture.")
+        kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
+        # the split count is baked into the captured launch: size it for a long-context batch
+        splits = self._choose_splits(bs, bs * min(self.max_context_len, 2048))
+        self.cuda_graph_splits[bs] = splits
+        self.forward_metadata = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, splits,
+                                                self.cuda_graph_workspace)
+
+    def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
+                                                forward_mode, spec_info, seq_lens_cpu):
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for graph replay.")
+        # no allocation, no host sync: two kernels into persistent buffers (triton_backend.py:544-566)
+        kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1  # triton_backend.py:629 -- padded rows attend one key (slot 0 sink via req_to_token)
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _pool_buffers(forward_batch, layer):
+        pool = forward_batch.token_to_kv_pool
+        return pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id)
+
+    def _save_kv(self, forward_batch, layer, k, v):
+        k_buf, v_buf = self._pool_buffers(forward_batch, layer)
+        if k.dtype != k_buf.dtype:
+            raise NotImplementedError("MiAttnBackend: fp8 KV cache (k_scale/v_scale) is a later row (SURVEY 8f-1)")
+        ops.kv_write(k_buf, v_buf, forward_batch.out_cache_loc, k, v)
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        if layer.qk_head_dim != layer.v_head_dim:
+            raise NotImplementedError("MiAttnBackend: qk_head_dim != v_head_dim (MLA) is out of scope")
+        o = q.new_empty(q.shape)
+        if save_kv_cache:
+            self._save_kv(forward_batch, layer, k, v)
+        k_buf, v_buf = self._pool_buffers(forward_batch, layer)
+        md = self.forward_metadata
+        ops.decode_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf,
+                             o.view(-1, layer.tp_q_head_num, layer.v_head_dim), md.kv_indptr, md.kv_indices,
+                             layer.scaling, getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace)
+        return o
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        if layer.qk_head_dim != layer.v_head_dim:
+            raise NotImplementedError("MiAttnBackend: qk_head_dim != v_head_dim (MLA) is out of scope")
+        o = q.new_empty(q.shape)
+        if save_kv_cache:
+            self._save_kv(forward_batch, layer, k, v)
+        k_buf, v_buf = self._pool_buffers(forward_batch, layer)
+        md = self.forward_metadata
+        causal = not (getattr(layer, "is_cross_attention", False)
+                      or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
+        window = getattr(layer, "sliding_window_size", -1)
+        window = -1 if window is None else int(window)
+        ops.extend_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                             k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                             v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
+                             o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
+                             md.kv_indptr, md.kv_indices, md.max_extend_len, layer.scaling,
+                             getattr(layer, "logit_cap", 0.0) or 0.0, causal, window if window > 0 else -1)
+        return o
+
+    def support_triton(self):
+        return False  # scheduler-side helpers then use their torch forms (srt/utils.py:204-205)

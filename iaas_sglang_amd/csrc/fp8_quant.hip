@@ -36,7 +36,7 @@ __device__ __forceinline__ uint2 quant8(const float (&f)[8], float inv) {
 // ------------------------------------------------------------------ per tensor
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, float* __restrict__ scale,
-                                                     int64_t M, int64_t K, int64_t ldx) {
+                                                     int64_t M, int64_t K, int64_t ldx, int raw) {
   __shared__ float red[4];
   const int64_t vec_per_row = K / 8;
   const int64_t total = M * vec_per_row;
@@ -54,16 +54,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, fl
   if (threadIdx.x == 0) {
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     // non-negative floats order like their bit patterns
-    atomicMax((unsigned int*)scale, __float_as_uint(mx / FP8_MAX));
+    atomicMax((unsigned int*)scale, __float_as_uint(raw ? mx : mx / FP8_MAX));
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void quant_tensor_kernel(const T* __restrict__ x, uint8_t* __restrict__ q,
                                                            const float* __restrict__ scale, int64_t M,
-                                                           int64_t K, int64_t ldx) {
+                                                           int64_t K, int64_t ldx, int raw) {
   const float s = *scale;
-  const float inv = s > 0.f ? 1.0f / s : 0.f;
+  // raw: *scale holds amax and the multiplier is 448/max(amax,1e-12) (input_to_float8,
+  // quantization/fp8_utils.py:314-325); else *scale is the dequant scale and we multiply by 1/scale
+  const float inv = raw ? FP8_MAX / fmaxf(s, 1e-12f) : (s > 0.f ? 1.0f / s : 0.f);
   const int64_t vec_per_row = K / 8;
   const int64_t total = M * vec_per_row;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -74,14 +76,21 @@ __global__ __launch_bounds__(256) void quant_tensor_kernel(const T* __restrict__
   }
 }
 
+// weight mode epilogue: amax -> dequant scale 1 / (448 / max(amax, 1e-12))
+__global__ void amax_to_inv_scale_kernel(float* scale) {
+  const float mult = FP8_MAX / fmaxf(*scale, 1e-12f);
+  *scale = 1.0f / mult;
+}
+
 extern "C" int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int64_t M, int64_t K,
                                        int64_t ldx, int is_static, int dtype, void* stream) {
   MI_CHECK_ARG(M >= 0 && K > 0);
   MI_CHECK_ARG(scale != nullptr);
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   hipStream_t st = (hipStream_t)stream;
+  MI_CHECK_ARG(is_static >= 0 && is_static <= 2);
   if (M == 0) {
-    if (!is_static && hipMemsetAsync(scale, 0, sizeof(float), st) != hipSuccess)
+    if (is_static != 1 && hipMemsetAsync(scale, 0, sizeof(float), st) != hipSuccess)
       MI_FAIL(MI_ERR_LAUNCH, "mi_fp8_quant_per_tensor: memset failed");
     return MI_OK;
   }
@@ -91,18 +100,23 @@ extern "C" int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int
   MI_CHECK_ARG((((uintptr_t)x & 15) | ((uintptr_t)q & 7)) == 0);
   const int64_t total = M * (K / 8);
   unsigned blocks = (unsigned)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
-  if (!is_static) {
+  const int raw = is_static == 2;
+  if (is_static != 1) {
     if (hipMemsetAsync(scale, 0, sizeof(float), st) != hipSuccess)
       MI_FAIL(MI_ERR_LAUNCH, "mi_fp8_quant_per_tensor: memset failed");
-    if (dtype == MI_BF16) absmax_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, scale, M, K, ldx);
-    else absmax_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, scale, M, K, ldx);
+    if (dtype == MI_BF16) absmax_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, scale, M, K, ldx, raw);
+    else absmax_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, scale, M, K, ldx, raw);
     MI_CHECK_LAUNCH();
   }
   if (dtype == MI_BF16)
-    quant_tensor_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (uint8_t*)q, scale, M, K, ldx);
+    quant_tensor_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (uint8_t*)q, scale, M, K, ldx, raw);
   else
-    quant_tensor_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (uint8_t*)q, scale, M, K, ldx);
+    quant_tensor_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (uint8_t*)q, scale, M, K, ldx, raw);
   MI_CHECK_LAUNCH();
+  if (raw) {
+    amax_to_inv_scale_kernel<<<1, 1, 0, st>>>(scale);
+    MI_CHECK_LAUNCH();
+  }
   return MI_OK;
 }
 

@@ -1,0 +1,268 @@
+"""Measurement / parity harness: the thinnest Llama-shaped caller of the hot path.
+
+It plays the role of the reference's MockModelRunner (python/sglang/test/attention/
+test_flashattn_backend.py:15-69) plus the per-layer call order of LlamaDecoderLayer
+(python/sglang/srt/models/llama.py:94-98,180-191,245-268): the plugins are driven only through
+their reference interfaces -- `quant_method.create_weights / process_weights_after_loading /
+apply` and `attn_backend.init_forward_metadata / forward` -- so what is timed here is what the
+unmodified srt model code would call.  Nothing in this file computes: it allocates, wires and
+calls (torch is used for the bf16 lm_head GEMM, embedding gather, argmax and collectives).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from ._compat import ForwardMode
+from .attention_backend import MiAttnBackend
+from .parallel import tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce
+
+
+@dataclass
+class ModelShape:
+    name: str
+    hidden: int
+    layers: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate: int
+    vocab: int
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    context_len: int = 8192
+
+
+LLAMA3_8B = ModelShape("Llama-3-8B", 4096, 32, 32, 8, 128, 14336, 128256)
+LLAMA2_7B = ModelShape("Llama-2-7B", 4096, 32, 32, 32, 128, 11008, 32000, rope_theta=10000.0, context_len=4096)
+LLAMA3_70B = ModelShape("Llama-3-70B", 8192, 80, 64, 8, 128, 28672, 128256)
+TINY = ModelShape("tiny-llama", 256, 2, 8, 2, 64, 512, 1000, context_len=512)
+
+
+class AttnLayer:
+    """The attributes of RadixAttention a backend reads (layers/radix_attention.py:37-80)."""
+
+    def __init__(self, num_heads, head_dim, scaling, num_kv_heads, layer_id, logit_cap=0.0):
+        self.tp_q_head_num, self.tp_k_head_num, self.tp_v_head_num = num_heads, num_kv_heads, num_kv_heads
+        self.head_dim = self.qk_head_dim = self.v_head_dim = head_dim
+        self.scaling, self.layer_id, self.logit_cap = scaling, layer_id, logit_cap
+        self.sliding_window_size = -1
+        self.is_cross_attention = False
+        self.k_scale = self.v_scale = None
+
+
+class KVPool:
+    """MHATokenToKVPool's data contract (mem_cache/memory_pool.py:236-249): per layer
+    [size + page_size, Hkv, D], slot 0 is the padding sink."""
+
+    def __init__(self, size, layer_num, head_num, head_dim, dtype, device, fill_random=False, seed=0):
+        self.size, self.dtype = size, dtype
+        g = torch.Generator(device=device).manual_seed(seed) if fill_random else None
+        self.k_buffer, self.v_buffer = [], []
+        for _ in range(layer_num):
+            for bufs in (self.k_buffer, self.v_buffer):
+                if fill_random:
+                    t = torch.empty(size + 1, head_num, head_dim, dtype=dtype, device=device)
+                    t.normal_(generator=g)
+                else:
+                    t = torch.zeros(size + 1, head_num, head_dim, dtype=dtype, device=device)
+                bufs.append(t)
+
+    def get_key_buffer(self, layer_id):
+        return self.k_buffer[layer_id]
+
+    def get_value_buffer(self, layer_id):
+        return self.v_buffer[layer_id]
+
+
+class Linear(torch.nn.Module):
+    """A LinearBase-shaped module: the quant method owns weights and forward (linear.py:208-229)."""
+
+    def __init__(self, in_features, out_partition_sizes: List[int], quant_method, params_dtype, bias=False):
+        super().__init__()
+        self.output_partition_sizes = out_partition_sizes
+        self.quant_method = quant_method
+        self.bias = None
+        quant_method.create_weights(self, in_features, out_partition_sizes, in_features, sum(out_partition_sizes),
+                                    params_dtype, weight_loader=None)
+
+    def forward(self, x):
+        return self.quant_method.apply(self, x, self.bias)
+
+
+def make_runner(shape: ModelShape, max_reqs, ctx, pool_tokens, dtype, device, tp=1, fill_kv=False, seed=0,
+                max_kv_splits=8):
+    """MockModelRunner-equivalent namespace (test_flashattn_backend.py:15-69, SURVEY 8b list)."""
+    Hkv = max(1, shape.num_kv_heads // tp)
+    mc = SimpleNamespace(num_attention_heads=shape.num_heads, num_key_value_heads=shape.num_kv_heads,
+                         context_len=ctx, head_dim=shape.head_dim, is_encoder_decoder=False,
+                         get_num_kv_heads=lambda tp_size: max(1, shape.num_kv_heads // tp_size))
+    r2t = SimpleNamespace(size=max_reqs, req_to_token=torch.zeros(max_reqs, ctx, dtype=torch.int32, device=device))
+    pool = KVPool(pool_tokens, shape.layers, Hkv, shape.head_dim, dtype, device, fill_random=fill_kv, seed=seed)
+    sa = SimpleNamespace(triton_attention_num_kv_splits=max_kv_splits, page_size=1,
+                         speculative_num_draft_tokens=None, speculative_num_steps=None)
+    return SimpleNamespace(device=device, dtype=dtype, model_config=mc, req_to_token_pool=r2t,
+                           token_to_kv_pool=pool, sliding_window_size=None, server_args=sa, tp_size=tp, gpu_id=0,
+                           kv_cache_dtype="auto", page_size=1)
+
+
+def rope_cache(head_dim, max_pos, base, device):
+    """RotaryEmbedding._compute_cos_sin_cache (layers/rotary_embedding.py:108-125), fp32 [max_pos, D]."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float, device=device) / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float, device=device)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).contiguous()
+
+
+class LlamaStack:
+    """qkv_proj -> rope -> attention -> o_proj -> (add+norm) -> gate_up -> silu*mul -> down, L times,
+    then final norm + lm_head.  `make_method()` returns a fresh LinearMethodBase per linear."""
+
+    def __init__(self, shape: ModelShape, make_method, dtype, device, tp=1, rank=0, group=None,
+                 weight_range=1e-3, seed=1234, weights_cpu_seeded=False):
+        self.shape, self.dtype, self.device = shape, dtype, device
+        self.tp, self.rank, self.group = tp, rank, group
+        s = shape
+        self.Hq, self.Hkv = s.num_heads // tp, max(1, s.num_kv_heads // tp)
+        D = s.head_dim
+        self.q_size, self.kv_size = self.Hq * D, self.Hkv * D
+        inter = s.intermediate // tp
+        self.inter = inter
+        gen = torch.Generator(device="cpu" if weights_cpu_seeded else device).manual_seed(seed + rank)
+
+        def dummy(*size):
+            # model_loader/weight_utils.py:750-779: uniform(-1e-3, 1e-3) dummy weights
+            if weights_cpu_seeded:
+                t = torch.rand(*size, generator=gen, dtype=torch.float32) * (2 * weight_range) - weight_range
+                return t.to(dtype).to(device)
+            t = torch.empty(*size, dtype=torch.float32, device=device).uniform_(-weight_range, weight_range, generator=gen)
+            return t.to(dtype)
+
+        def linear(k, outs):
+            lin = Linear(k, outs, make_method(), dtype).to(device)
+            self._init_linear(lin, dummy)
+            lin.quant_method.process_weights_after_loading(lin)
+            return lin
+
+        self.layers = []
+        for i in range(s.layers):
+            self.layers.append(SimpleNamespace(
+                input_norm=(torch.ones(s.hidden, dtype=dtype, device=device) + dummy(s.hidden)),
+                post_norm=(torch.ones(s.hidden, dtype=dtype, device=device) + dummy(s.hidden)),
+                qkv=linear(s.hidden, [self.q_size, self.kv_size, self.kv_size]),
+                o=linear(self.q_size, [s.hidden]),
+                gate_up=linear(s.hidden, [inter, inter]),
+                down=linear(inter, [s.hidden]),
+                attn=AttnLayer(self.Hq, D, D ** -0.5, self.Hkv, i)))
+        self.final_norm = torch.ones(s.hidden, dtype=dtype, device=device) + dummy(s.hidden)
+        self.vocab_shard = s.vocab // tp
+        self.lm_head = dummy(self.vocab_shard, s.hidden)           # bf16, unquantised (logits_processor.py:423-480)
+        self.embed = dummy(s.vocab, s.hidden)                       # token ids -> hidden (plumbing, replicated)
+        self.cos_sin = rope_cache(D, s.context_len, s.rope_theta, device)
+
+    @staticmethod
+    def _init_linear(lin, dummy):
+        """Fill whatever checkpoint-layout parameters the method created with synthetic data."""
+        names = dict(lin.named_parameters())
+        if "weight" in names:                      # fp8 from a bf16 checkpoint: plain weight
+            w = names["weight"]
+            if w.dtype in (torch.bfloat16, torch.float16):
+                w.data.copy_(dummy(*w.shape))
+            else:
+                raise NotImplementedError("serialized-fp8 synthetic init is done by the tests")
+        if "qweight" in names:                     # int4: random nibbles, small scales
+            dev = names["qweight"].device
+            g = torch.Generator(device=dev).manual_seed(1234)
+            for n in ("qweight", "qzeros"):
+                p = names[n]
+                p.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape, dtype=torch.int32, device=dev, generator=g))
+            if type(lin.quant_method).__name__.startswith("GPTQ"):
+                names["qzeros"].data.bitwise_and_(0x66666666)  # stored zero <= 14 so z+1 is a nibble
+            sc = names["scales"]
+            sc.data.copy_((torch.rand(sc.shape, device=dev, generator=g) * 1e-2 / 8).to(sc.dtype))
+
+    def _all_reduce(self, x):
+        return tensor_model_parallel_all_reduce(x, self.tp, self.group)   # RowParallelLinear (linear.py:1376-1378)
+
+    def forward(self, hidden, positions, fb, backend):
+        """hidden [T, H] -> logits [T, vocab]; follows llama.py:245-268 with the fused add+norm form."""
+        s = self.shape
+        residual = None
+        for L in self.layers:
+            if residual is None:
+                residual = hidden
+                x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps)
+            else:
+                x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps, residual=residual)
+            qkv = L.qkv(x)
+            q, k, v = qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size], qkv[:, self.q_size + self.kv_size:]
+            ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
+            a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
+                                L.attn, fb)
+            hidden = self._all_reduce(L.o(a))
+            x = ops.rmsnorm(hidden, L.post_norm, s.rms_eps, residual=residual)
+            gu = L.gate_up(x)
+            hidden = self._all_reduce(L.down(ops.silu_and_mul(gu)))
+        x = ops.rmsnorm(hidden, self.final_norm, s.rms_eps, residual=residual)
+        logits = torch.matmul(x, self.lm_head.t())
+        return tensor_model_parallel_all_gather(logits, self.tp, self.group)   # logits_processor.py:464-477
+
+
+def make_decode_batch(runner, backend, batch, seq_len, device, scattered=True, seed=0, ragged=None):
+    """A decode ForwardBatch at steady state: every request already holds `seq_len` tokens
+    (the token being generated included, schedule_batch.py:1541-1546), slots scattered over the
+    pool by a random permutation (worst-case gather) or contiguous."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lens = torch.full((batch,), seq_len, dtype=torch.int64) if ragged is None else ragged.to(torch.int64)
+    total = int(lens.sum())
+    assert total <= runner.token_to_kv_pool.size
+    slots = (torch.randperm(total, generator=g) if scattered else torch.arange(total)) + 1
+    r2t = runner.req_to_token_pool.req_to_token
+    off = 0
+    out_loc = []
+    for i in range(batch):
+        L = int(lens[i])
+        r2t[i, :L] = slots[off: off + L].to(torch.int32).to(device)
+        out_loc.append(int(slots[off + L - 1]))
+        off += L
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=batch,
+                         req_pool_indices=torch.arange(batch, dtype=torch.int64, device=device),
+                         seq_lens=lens.to(device), seq_lens_sum=total, seq_lens_cpu=lens,
+                         out_cache_loc=torch.tensor(out_loc, dtype=torch.int64, device=device),
+                         req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                         attn_backend=backend, spec_info=None,
+                         positions=(lens - 1).to(device))
+    return fb
+
+
+def make_extend_batch(runner, backend, prefix_lens, extend_lens, device, seed=0):
+    """An EXTEND ForwardBatch (schedule_batch.py:1119-1309): prefix slots already in req_to_token,
+    new tokens get fresh slots written to req_to_token[pre:seq] and out_cache_loc."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    B = len(prefix_lens)
+    lens = [p + e for p, e in zip(prefix_lens, extend_lens)]
+    total = sum(lens)
+    assert total <= runner.token_to_kv_pool.size
+    slots = torch.randperm(total, generator=g) + 1
+    r2t = runner.req_to_token_pool.req_to_token
+    off, out_loc, pos = 0, [], []
+    for i in range(B):
+        r2t[i, : lens[i]] = slots[off: off + lens[i]].to(torch.int32).to(device)
+        out_loc.append(slots[off + prefix_lens[i]: off + lens[i]])
+        pos.append(torch.arange(prefix_lens[i], lens[i]))
+        off += lens[i]
+    return SimpleNamespace(forward_mode=ForwardMode.EXTEND, batch_size=B,
+                           req_pool_indices=torch.arange(B, dtype=torch.int64, device=device),
+                           seq_lens=torch.tensor(lens, dtype=torch.int64, device=device), seq_lens_sum=total,
+                           seq_lens_cpu=torch.tensor(lens, dtype=torch.int64),
+                           extend_prefix_lens=torch.tensor(prefix_lens, dtype=torch.int32, device=device),
+                           extend_seq_lens=torch.tensor(extend_lens, dtype=torch.int32, device=device),
+                           extend_prefix_lens_cpu=list(prefix_lens), extend_seq_lens_cpu=list(extend_lens),
+                           out_cache_loc=torch.cat(out_loc).to(torch.int64).to(device),
+                           req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                           attn_backend=backend, spec_info=None, positions=torch.cat(pos).to(device))

@@ -145,16 +145,19 @@ def merge_state(o_a, lse_a, o_b, lse_b, out=None, out_lse=None) -> Tuple[torch.T
 
 # --------------------------------------------------------------------------- FP8
 def fp8_quant_per_tensor(x: torch.Tensor, scale: Optional[torch.Tensor] = None,
-                         out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """scale None -> dynamic (scale = absmax/448 written to a new fp32 [1]); else static."""
+                         out: Optional[torch.Tensor] = None, weight_mode: bool = False
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scale None -> dynamic (scale = absmax/448 written to a new fp32 [1]); else static.
+    weight_mode: the reference's `input_to_float8` arithmetic (multiplier 448/amax, returns 1/multiplier)."""
     assert x.dim() == 2 and x.stride(1) == 1
     M, K = x.shape
-    is_static = scale is not None
+    assert not (weight_mode and scale is not None)
+    is_static = 2 if weight_mode else int(scale is not None)
     if scale is None:
         scale = torch.empty(1, dtype=torch.float32, device=x.device)
     assert scale.dtype == torch.float32 and scale.numel() == 1
     out = torch.empty(M, K, dtype=FP8_DTYPE, device=x.device) if out is None else out
-    check(lib.mi_fp8_quant_per_tensor(_ptr(x), _ptr(out), _ptr(scale), M, K, x.stride(0), int(is_static), _dt(x),
+    check(lib.mi_fp8_quant_per_tensor(_ptr(x), _ptr(out), _ptr(scale), M, K, x.stride(0), is_static, _dt(x),
                                       _stream()), "mi_fp8_quant_per_tensor")
     return out, scale
 
@@ -237,4 +240,39 @@ def w4_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Ten
     out = torch.empty(K, N, dtype=scales.dtype, device=scales.device)
     check(lib.mi_w4_dequantize(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(out), N, K,
                                int(group_size), int(layout), _dt(scales), _stream()), "mi_w4_dequantize")
+    return out
+
+
+# ------------------------------------------------------------ layer glue ("next" rows)
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = rmsnorm(x (+ residual)) * weight; residual (if given) is updated in place to x + residual."""
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous() and weight.dtype == x.dtype
+    M, H = x.shape
+    out = torch.empty_like(x) if out is None else out
+    if residual is not None:
+        assert residual.shape == x.shape and residual.stride(1) == 1 and residual.dtype == x.dtype
+    check(lib.mi_rmsnorm(_ptr(x), _ptr(residual), _ptr(weight), _ptr(out), M, H, x.stride(0),
+                         residual.stride(0) if residual is not None else 0, out.stride(0), float(eps), _dt(x),
+                         _stream()), "mi_rmsnorm")
+    return out
+
+
+def rope_neox_(q: torch.Tensor, k: torch.Tensor, positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+               head_dim: int) -> None:
+    """In-place NeoX RoPE on q [T, Hq*D] and k [T, Hkv*D] (row-strided views allowed)."""
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and positions.dtype == torch.int64
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim
+    T = q.shape[0]
+    check(lib.mi_rope_neox(_ptr(q), _ptr(k), _ptr(positions), _ptr(cos_sin_cache), T, q.shape[1] // head_dim,
+                           k.shape[1] // head_dim, head_dim, q.stride(0), k.stride(0), _dt(q), _stream()),
+          "mi_rope_neox")
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, I2 = x.shape
+    out = torch.empty(M, I2 // 2, dtype=x.dtype, device=x.device) if out is None else out
+    check(lib.mi_silu_and_mul(_ptr(x), _ptr(out), M, I2 // 2, x.stride(0), out.stride(0), _dt(x), _stream()),
+          "mi_silu_and_mul")
     return out

@@ -112,13 +112,16 @@ int mi_merge_state(const void* o_a, const float* lse_a, const void* o_b, const f
 
 /* ------------------------------------------------------------- FP8 (OCP e4m3fn) */
 
-/* Per-tensor quant: is_static ? scale given : scale[0] = absmax(x)/448 (written).
- *   q = sat(x * (1/scale)) -> fp8.  x [M,K] row stride ldx elements, q contiguous [M,K].
- *   In dynamic mode the call itself resets `scale` on the stream before reducing into it.
- * replaces: sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:96-123
- * (and vllm ops.scaled_fp8_quant per-tensor as called at fp8_utils.py:669-674). */
+/* Per-tensor quant.  x [M,K] row stride ldx elements, q contiguous [M,K]; `mode`:
+ *   0 dynamic activation : scale[0] = absmax(x)/448 (written), q = sat(x * (1/scale))
+ *   1 static             : scale given,                         q = sat(x * (1/scale))
+ *   2 dynamic weight     : q = sat(x * (448/max(absmax,1e-12))), scale[0] = 1/(448/amax) (written)
+ *   In modes 0/2 the call itself resets `scale` on the stream before reducing into it.
+ * replaces: 0/1 sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:96-123
+ * (and vllm ops.scaled_fp8_quant per-tensor as called at fp8_utils.py:669-674);
+ * 2 input_to_float8, quantization/fp8_utils.py:310-326 (weights of bf16 checkpoints, fp8.py:359). */
 int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int64_t M, int64_t K,
-                            int64_t ldx, int is_static, int dtype, void* stream);
+                            int64_t ldx, int mode, int dtype, void* stream);
 
 /* Per-token quant: scales[m] = absmax(x[m,:])/448.
  * replaces: sgl_per_token_quant_fp8, sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:78-106. */
@@ -167,6 +170,29 @@ int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native,
 int mi_w4_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* scales,
                      const int32_t* g_idx /* nullable */, void* w_out, int64_t N, int64_t K,
                      int64_t group_size, int layout, int dtype, void* stream);
+
+/* ------------------------------------------ layer glue (SURVEY 8f "next" rows 1-2) */
+
+/* (fused add +) RMSNorm, one row per token: x32 = x (+ residual); residual <- x32 (in place,
+ * nullable); out = x32 * rsqrt(mean(x32^2)+eps) * weight.
+ * replaces: RMSNorm.forward_native, layers/layernorm.py:128-146 (sgl-kernel
+ * fused_add_rmsnorm / rmsnorm, csrc/elementwise/fused_add_rms_norm_kernel.cu). */
+int mi_rmsnorm(const void* x, void* residual /* nullable, in/out */, const void* weight, void* out,
+               int64_t M, int64_t H, int64_t ldx, int64_t ldr, int64_t ldo, float eps, int dtype,
+               void* stream);
+
+/* In-place NeoX rotary embedding on q [tokens,Hq,D] and k [tokens,Hkv,D] (rotary_dim == D);
+ * cos_sin_cache fp32 [max_pos, D] = [cos(D/2) | sin(D/2)], positions int64 [tokens].
+ * replaces: RotaryEmbedding.forward_native, layers/rotary_embedding.py:49-74,138-166
+ * (sgl-kernel csrc/elementwise/rope.cu). */
+int mi_rope_neox(void* q, void* k, const int64_t* positions, const float* cos_sin_cache,
+                 int64_t tokens, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                 int64_t ldq, int64_t ldk, int dtype, void* stream);
+
+/* out[M,I] = silu(x[:, :I]) * x[:, I:2I].
+ * replaces: SiluAndMul.forward_native, layers/activation.py:56-58 (csrc/elementwise/activation.cu). */
+int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx, int64_t ldo,
+                    int dtype, void* stream);
 
 #ifdef __cplusplus
 }

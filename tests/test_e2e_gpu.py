@@ -1,0 +1,146 @@
+"""End-to-end parity through the plugin surfaces: a tiny Llama-shaped stack (extend, then decode
+steps) on the HIP path vs the same stack spelled with the CPU oracle.  North-star bar: max-abs
+logit error < 1e-3 with the reference's dummy weights (uniform +-1e-3)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention as oa  # noqa: E402
+from oracle import elementwise as oe  # noqa: E402
+from oracle import quant as oq  # noqa: E402
+
+DEV = "cuda"
+
+
+def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_lens, pre, ext, loc, decode):
+    """Same layer order as harness.LlamaStack.forward, every op from oracle/ (CPU)."""
+    D, Hq, Hkv = shape.head_dim, shape.num_heads, shape.num_kv_heads
+    cache = oe.rope_cos_sin_cache(D, shape.context_len, shape.rope_theta)
+    residual = None
+    for li, W in enumerate(stack_w["layers"]):
+        if residual is None:
+            residual = hidden
+            x = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps)
+        else:
+            x, residual = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps, residual)
+        qkv = oq.fp8_linear(x, W["qkv_w"], W["qkv_s"])
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        q, k = oe.rope_neox(positions, q.contiguous(), k.contiguous(), cache, D)
+        k3, v3 = k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D)
+        if decode:
+            a = oa.forward_decode(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, loc, Hq, Hkv, D ** -0.5)
+        else:
+            a = oa.forward_extend(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, pre, ext, loc, Hq, Hkv, D ** -0.5)
+        hidden = oq.fp8_linear(a, W["o_w"], W["o_s"])
+        x, residual = oe.rmsnorm(hidden, W["post_norm"], shape.rms_eps, residual)
+        gu = oq.fp8_linear(x, W["gu_w"], W["gu_s"])
+        hidden = oq.fp8_linear(oe.silu_and_mul(gu), W["down_w"], W["down_s"])
+    x, _ = oe.rmsnorm(hidden, stack_w["final_norm"], shape.rms_eps, residual)
+    return (x.float() @ stack_w["lm_head"].float().t())
+
+
+@pytest.mark.parametrize("weight_range,tol", [(1e-3, 1e-3), (0.05, 5e-2)])
+def test_tiny_llama_fp8_extend_then_decode(weight_range, tol):
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import Fp8Config
+
+    shape, dtype = H.TINY, torch.bfloat16
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=False, activation_scheme="dynamic")
+    runner = H.make_runner(shape, max_reqs=8, ctx=128, pool_tokens=600, dtype=dtype, device=DEV)
+    backend = MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, DEV, weight_range=weight_range,
+                         weights_cpu_seeded=True)
+    # the quantised weights as the oracle sees them ([K,N] fp8 view + scale), copied off the device
+    W = {"layers": [], "final_norm": stack.final_norm.cpu(), "lm_head": stack.lm_head.cpu()}
+    for L in stack.layers:
+        W["layers"].append({"input_norm": L.input_norm.cpu(), "post_norm": L.post_norm.cpu(),
+                            "qkv_w": L.qkv.weight.cpu(), "qkv_s": L.qkv.weight_scale.cpu(),
+                            "o_w": L.o.weight.cpu(), "o_s": L.o.weight_scale.cpu(),
+                            "gu_w": L.gate_up.weight.cpu(), "gu_s": L.gate_up.weight_scale.cpu(),
+                            "down_w": L.down.weight.cpu(), "down_s": L.down.weight_scale.cpu()})
+    g = torch.Generator().manual_seed(0)
+    prefix, extend = [0, 0, 0], [37, 5, 64]
+    fb = H.make_extend_batch(runner, backend, prefix, extend, DEV, seed=1)
+    E = sum(extend)
+    hidden = torch.randn(E, shape.hidden, generator=g).to(dtype)
+    backend.init_forward_metadata(fb)
+    logits = stack.forward(hidden.to(DEV), fb.positions, fb, backend)
+    kc = [torch.zeros_like(b).cpu() for b in runner.token_to_kv_pool.k_buffer]
+    vc = [torch.zeros_like(b).cpu() for b in runner.token_to_kv_pool.v_buffer]
+    r2t = runner.req_to_token_pool.req_to_token.cpu()
+    ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc, r2t, fb.req_pool_indices.cpu(),
+                          fb.seq_lens.cpu(), fb.extend_prefix_lens.cpu(), fb.extend_seq_lens.cpu(),
+                          fb.out_cache_loc.cpu(), decode=False)
+    assert float((logits.float().cpu() - ref).abs().max()) < tol
+    # the KV pool after prefill is what the oracle wrote (bf16 rounding of slightly different fp8 sums aside)
+    for li in range(shape.layers):
+        torch.testing.assert_close(runner.token_to_kv_pool.k_buffer[li].cpu().float(), kc[li].float(),
+                                   atol=tol, rtol=2e-2)
+    # two decode steps on top (seq_lens grow by one, new slot per request)
+    lens = [p + e for p, e in zip(prefix, extend)]
+    next_slot = sum(lens) + 1
+    for step in range(2):
+        lens = [L + 1 for L in lens]
+        B = len(lens)
+        loc = torch.arange(next_slot, next_slot + B, dtype=torch.int64)
+        next_slot += B
+        for i in range(B):
+            runner.req_to_token_pool.req_to_token[i, lens[i] - 1] = int(loc[i])
+        fb.forward_mode = H.ForwardMode.DECODE
+        fb.seq_lens = torch.tensor(lens, dtype=torch.int64, device=DEV)
+        fb.seq_lens_sum = sum(lens)
+        fb.out_cache_loc = loc.to(DEV)
+        fb.positions = (fb.seq_lens - 1)
+        hidden = torch.randn(B, shape.hidden, generator=g).to(dtype)
+        backend.init_forward_metadata(fb)
+        logits = stack.forward(hidden.to(DEV), fb.positions, fb, backend)
+        ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc,
+                              runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
+                              fb.seq_lens.cpu(), None, None, loc, decode=True)
+        assert float((logits.float().cpu() - ref).abs().max()) < tol
+
+
+def test_backend_graph_capture_replay_matches_eager():
+    """Decode under hipGraph: capture with one batch, replay with other seq_lens / slots
+    (cuda_graph_runner.py:456-696 protocol: persistent inputs, metadata replay, padded rows)."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+
+    shape, dtype = H.TINY, torch.bfloat16
+    runner = H.make_runner(shape, max_reqs=8, ctx=512, pool_tokens=3000, dtype=dtype, device=DEV, fill_kv=True)
+    backend = MiAttnBackend(runner)
+    bs = 4
+    backend.init_cuda_graph_state(bs, bs)
+    layer = H.AttnLayer(shape.num_heads, shape.head_dim, shape.head_dim ** -0.5, shape.num_kv_heads, 0)
+    g = torch.Generator().manual_seed(0)
+    # persistent graph inputs
+    rpi = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    seq_lens = torch.full((bs,), backend.get_cuda_graph_seq_len_fill_value(), dtype=torch.int64, device=DEV)
+    out_loc = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    q = torch.zeros(bs, shape.num_heads * shape.head_dim, dtype=dtype, device=DEV)
+    k = torch.zeros(bs, shape.num_kv_heads, shape.head_dim, dtype=dtype, device=DEV)
+    v = torch.zeros_like(k)
+    fb = H.make_decode_batch(runner, backend, bs, 300, DEV, seed=2)
+    fb.req_pool_indices, fb.seq_lens, fb.out_cache_loc = rpi, seq_lens, out_loc
+    backend.init_forward_metadata_capture_cuda_graph(bs, bs, rpi, seq_lens, None, H.ForwardMode.DECODE, None)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = backend.forward(q, k, v, layer, fb)
+    for trial, lens in enumerate([[300, 17, 450, 1], [5, 5, 5, 5], [511, 300, 2, 64]]):
+        fb2 = H.make_decode_batch(runner, MiAttnBackend(runner), bs, 0, DEV, seed=10 + trial,
+                                  ragged=torch.tensor(lens))
+        rpi.copy_(fb2.req_pool_indices); seq_lens.copy_(fb2.seq_lens); out_loc.copy_(fb2.out_cache_loc)
+        q.copy_(torch.randn(q.shape, generator=g).to(dtype)); k.copy_(torch.randn(k.shape, generator=g).to(dtype))
+        v.copy_(torch.randn(v.shape, generator=g).to(dtype))
+        backend.init_forward_metadata_replay_cuda_graph(bs, rpi, seq_lens, sum(lens), None, H.ForwardMode.DECODE,
+                                                        None, fb2.seq_lens_cpu)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        eager_backend = fb2.attn_backend
+        eager_backend.init_forward_metadata(fb2)
+        want = eager_backend.forward(q, k, v, layer, fb2)     # KV write is idempotent (same k,v,slots)
+        torch.testing.assert_close(got.float(), want.float(), atol=4e-3, rtol=2 ** -7)

@@ -164,3 +164,12 @@ def test_gptq_fused_gemm_vs_oracle(act_order):
     torch.testing.assert_close(y.cpu().float(), ref, rtol=2 ** -9, atol=3e-2)
     Wd = o_.w4_dequantize(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), g, MI_W4_GPTQ, g_idx.to(DEV))
     assert torch.equal(Wd.cpu(), W.to(torch.float16))
+
+
+def test_input_to_float8_weight_mode_golden(golden_quant):
+    # fp8.py:359-366 path for bf16 checkpoints: bit-exact with the reference's input_to_float8
+    o_ = ops()
+    c = golden_quant["input_to_float8"]
+    q, inv = o_.fp8_quant_per_tensor(c["x"].to(DEV), weight_mode=True)
+    assert torch.equal(q.cpu().view(torch.uint8), c["q"])
+    assert torch.equal(inv.cpu().reshape(()), c["inv_scale"])
