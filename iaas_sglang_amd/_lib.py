@@ -33,7 +33,8 @@ SIGNATURES = {
     "mi_merge_state": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "mi_fp8_quant_per_tensor": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_fp8_quant_per_token": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),
-    "mi_fp8_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _p]),
+    "mi_fp8_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _p, _i64, _p]),
+    "mi_fp8_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "mi_w4_repack": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_rmsnorm": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),

@@ -83,34 +83,34 @@ __global__ __launch_bounds__(256) void extend_attn_kernel(const ExtendParams p) 
 
   // ---- staging: thread -> (row srow + TPR*pass, 16-byte chunk schunk)
   const int srow = tid / (D / 8), schunk = tid % (D / 8);
-  uint4 kreg[NPASS], vreg[NPASS];
-  auto stage_load = [&](int32_t tile) {
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      int32_t kp = tile * 32 + srow + TPR * ps;
-      kp = min(kp, n_keys - 1);
-      const T *kr, *vr;
-      if (kp < prefix) {
-        const int64_t slot = p.kv_indices[kv_base + kp];
-        kr = (const T*)p.k_buf + slot * p.stride_k_slot + (int64_t)hk * D;
-        vr = (const T*)p.v_buf + slot * p.stride_v_slot + (int64_t)hk * D;
-      } else {
-        const int64_t t = q_start + (kp - prefix);
-        kr = (const T*)p.k_ext + t * p.stride_kx_tok + (int64_t)hk * D;
-        vr = (const T*)p.v_ext + t * p.stride_vx_tok + (int64_t)hk * D;
-      }
-      kreg[ps] = *(const uint4*)(kr + schunk * 8);
-      vreg[ps] = *(const uint4*)(vr + schunk * 8);
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int r = srow + TPR * ps;
-      *(uint4*)(ks_lds + r * ROW + schunk * 16) = kreg[ps];
-      *(uint4*)(vs_lds + r * ROW + schunk * 16) = vreg[ps];
-    }
-  };
+  // named registers + macros (arrays captured by lambdas / indexed in loops ended up in scratch)
+  uint4 kreg0, vreg0, kreg1, vreg1;
+#define STAGE_LOAD_ONE(tile_, ps_, KR, VR)                                                    \
+  {                                                                                           \
+    int32_t kp_ = (tile_) * 32 + srow + TPR * (ps_);                                          \
+    kp_ = min(kp_, n_keys - 1);                                                               \
+    const bool in_pool_ = kp_ < prefix;                                                       \
+    const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + min(kp_, max(prefix - 1, 0))] : 0; \
+    const int64_t t_ = q_start + max(kp_ - prefix, 0);                                        \
+    const T* kr_ = in_pool_ ? (const T*)p.k_buf + slot_ * p.stride_k_slot : (const T*)p.k_ext + t_ * p.stride_kx_tok; \
+    const T* vr_ = in_pool_ ? (const T*)p.v_buf + slot_ * p.stride_v_slot : (const T*)p.v_ext + t_ * p.stride_vx_tok; \
+    KR = *(const uint4*)(kr_ + (int64_t)hk * D + schunk * 8);                                 \
+    VR = *(const uint4*)(vr_ + (int64_t)hk * D + schunk * 8);                                 \
+  }
+#define STAGE_LOAD(tile_)                                       \
+  {                                                             \
+    STAGE_LOAD_ONE(tile_, 0, kreg0, vreg0);                     \
+    if constexpr (NPASS == 2) STAGE_LOAD_ONE(tile_, 1, kreg1, vreg1); \
+  }
+#define STAGE_WRITE()                                                         \
+  {                                                                           \
+    *(uint4*)(ks_lds + srow * ROW + schunk * 16) = kreg0;                     \
+    *(uint4*)(vs_lds + srow * ROW + schunk * 16) = vreg0;                     \
+    if constexpr (NPASS == 2) {                                               \
+      *(uint4*)(ks_lds + (srow + TPR) * ROW + schunk * 16) = kreg1;           \
+      *(uint4*)(vs_lds + (srow + TPR) * ROW + schunk * 16) = vreg1;           \
+    }                                                                         \
+  }
 
   f32x4 acc[DB];
 #pragma unroll
@@ -120,13 +120,13 @@ __global__ __launch_bounds__(256) void extend_attn_kernel(const ExtendParams p) 
   // last key (exclusive) this WAVE can see: lets early waves skip fully masked tiles
   const int32_t wave_keys = p.causal ? prefix + min(ext_len, tok0 + 16) : n_keys;
 
-  stage_load(0);
-  stage_write();
+  STAGE_LOAD(0);
+  STAGE_WRITE();
   __syncthreads();
 
   for (int32_t tile = 0; tile < n_tiles; ++tile) {
     const bool has_next = tile + 1 < n_tiles;
-    if (has_next) stage_load(tile + 1);
+    if (has_next) STAGE_LOAD(tile + 1);
 
     if (wave_active && tile * 32 < wave_keys) {
       // ---- S^T = K . Q^T for the two 16-key halves
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void extend_attn_kernel(const ExtendParams p) 
     }
     __syncthreads();  // everyone is done reading this tile
     if (has_next) {
-      stage_write();
+      STAGE_WRITE();
       __syncthreads();
     }
   }

@@ -10,6 +10,7 @@
 // consecutive n of one output row (one 8-byte store).
 // Bound at decode (M <= 128): HBM (weights read once); at prefill: MFMA.
 #include "common.h"
+#include <stdlib.h>
 
 typedef long fp8x8_t;  // 8 fp8 values = one MFMA 16x16x32 fp8 operand
 
@@ -21,7 +22,7 @@ struct GemmParams {
   const void* bias;
   void* out;
   int64_t M, N, K, lda, ldb, ldo;
-  int sa_row, sb_row;
+  int sa_row, sb_row, rotate;
 };
 
 template <typename OutT, int MT>
@@ -108,8 +109,354 @@ __global__ __launch_bounds__(256) void fp8_gemm_kernel(const GemmParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Decode-shaped GEMM (M <= 128): weights are read exactly once, every CU gets a 16-column strip.
+//   workgroup = NW waves, tile = (MT*16 rows) x 16 columns x all of K; wave w owns the 128-byte
+//   k-chunks c = w, w+NW, ... (adjacent waves read adjacent chunks of the same 16 weight rows, so
+//   the workgroup streams whole DRAM pages).  Every operand goes straight from HBM/L2 into MFMA
+//   fragments: a lane holds bytes [16q,16q+16) and [64+16q,64+16q+16) of its row's chunk (each
+//   wave load covers 64 contiguous bytes of 16 rows); the same k-slot assignment is used for both
+//   operands, which is all the MFMA needs.  One v_mfma_scale_f32_16x16x128_f8f6f4 per (m-tile,
+//   chunk) with unit block scales (E8M0 0x7F) -- twice the rate of the unscaled fp8 MFMA.
+//   Next chunk's loads are issued before the current chunk's MFMAs (register double buffer).
+//   The NW partial tiles are summed through LDS and wave t applies the epilogue of m-tile t.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <typename OutT, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void fp8_gemm_skinny_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [NW][MT][64 lanes][4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const int64_t K = p.K;
+  const int64_t KC = (K + 127) / 128;
+
+  const uint8_t* wp = p.b + min(n0 + r16, p.N - 1) * p.ldb + 16 * q;
+  const uint8_t* xp[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) xp[t] = p.a + min((int64_t)t * 16 + r16, p.M - 1) * p.lda + 16 * q;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // chunk j of this wave is c = wave + NW*j over the KF full chunks; workgroups start at different
+  // j so that at any instant the chip touches many different weight/activation columns
+  const int64_t KF = K / 128;
+  const int64_t J = (KF > wave) ? (KF - wave + NW - 1) / NW : 0;
+  const int64_t rot = p.rotate ? (int64_t)(blockIdx.x % (unsigned)(J > 0 ? J : 1)) : 0;
+
+  // Two register buffers (a/b) as plain arrays + macros: no structs/lambdas, so nothing can end up
+  // in scratch.  Loads never sit under a condition (a per-load select makes hipcc branch and drain
+  // vmcnt around every load): past the end they re-read the last chunk, which is harmless.
+  uint4 wa0, wa1, wb0, wb1, xa0[MT], xa1[MT], xb0[MT], xb1[MT];
+#define SK_CHUNK(j_) (wave + NW * (((j_) + rot) >= J ? ((j_) + rot) - J : ((j_) + rot)))
+#define SK_LOAD(W0, W1, X0, X1, c_)                         \
+  {                                                         \
+    const int64_t kb_ = (int64_t)(c_) * 128;                \
+    W0 = *(const uint4*)(wp + kb_);                         \
+    W1 = *(const uint4*)(wp + kb_ + 64);                    \
+    const int64_t kx_ = p.rotate == 2 ? 0 : kb_;            \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t) {        \
+      X0[t] = *(const uint4*)(xp[t] + kx_);                 \
+      X1[t] = *(const uint4*)(xp[t] + kx_ + 64);            \
+    }                                                       \
+  }
+#define SK_MMA(W0, W1, X0, X1)                                                                          \
+  {                                                                                                     \
+    const i32x8 wf_ = {(int)W0.x, (int)W0.y, (int)W0.z, (int)W0.w, (int)W1.x, (int)W1.y, (int)W1.z, (int)W1.w}; \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                    \
+      const i32x8 xf_ = {(int)X0[t].x, (int)X0[t].y, (int)X0[t].z, (int)X0[t].w,                        \
+                         (int)X1[t].x, (int)X1[t].y, (int)X1[t].z, (int)X1[t].w};                       \
+      acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf_, xf_, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+    }                                                                                                   \
+  }
+  if (J > 0) {
+    SK_LOAD(wa0, wa1, xa0, xa1, SK_CHUNK(0));
+    for (int64_t j = 0; j + 1 < J; j += 2) {
+      SK_LOAD(wb0, wb1, xb0, xb1, SK_CHUNK(j + 1));
+      SK_MMA(wa0, wa1, xa0, xa1);
+      const int64_t jn = j + 2 < J ? j + 2 : J - 1;
+      SK_LOAD(wa0, wa1, xa0, xa1, SK_CHUNK(jn));
+      SK_MMA(wb0, wb1, xb0, xb1);
+    }
+    if (J & 1) SK_MMA(wa0, wa1, xa0, xa1);
+  }
+  if (KF < KC && wave == (int)(KF % NW)) {  // partial last chunk (K % 128 != 0): zero-fill beyond K
+    const int64_t kb = KF * 128;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const bool ok0 = kb + 16 * q < K, ok1 = kb + 64 + 16 * q < K;
+    wa0 = z; wa1 = z;
+    if (ok0) wa0 = *(const uint4*)(wp + kb);
+    if (ok1) wa1 = *(const uint4*)(wp + kb + 64);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      xa0[t] = z; xa1[t] = z;
+      if (ok0) xa0[t] = *(const uint4*)(xp[t] + kb);
+      if (ok1) xa1[t] = *(const uint4*)(xp[t] + kb + 64);
+    }
+    SK_MMA(wa0, wa1, xa0, xa1);
+  }
+#undef SK_CHUNK
+#undef SK_LOAD
+#undef SK_MMA
+
+  // ---- cross-wave (split-K) reduction through LDS, then the scale/bias epilogue
+#pragma unroll
+  for (int t = 0; t < MT; ++t) *(f32x4*)(red + ((wave * MT + t) * 64 + lane) * 4) = acc[t];
+  __syncthreads();
+  for (int t = wave; t < MT; t += NW) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += *(const f32x4*)(red + ((w * MT + t) * 64 + lane) * 4);
+    const int64_t m = (int64_t)t * 16 + r16;
+    const int64_t nb = n0 + 4 * q;
+    if (m < p.M) {
+      const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+      OutT* o = (OutT*)p.out + m * p.ldo + nb;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = min(nb + r, p.N - 1);
+        const float sbv = p.sb_row ? p.sb[n] : p.sb[0];
+        const float bv = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+        v[r] = sum[r] * sav * sbv + bv;
+      }
+      if (nb + 3 < p.N && (p.ldo & 3) == 0) {
+        *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < p.N) o[r] = (OutT)v[r];
+      }
+    }
+  }
+}
+
+template <typename OutT, int MT>
+static void launch_skinny(const GemmParams& p, hipStream_t st) {
+  constexpr int NW = 8;
+  const size_t lds = (size_t)NW * MT * 64 * 4 * sizeof(float);
+  fp8_gemm_skinny_kernel<OutT, MT, NW><<<(unsigned)cdiv64(p.N, 16), NW * 64, lds, st>>>(p);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Decode-shaped GEMM v3 ("x-stationary"): the activation slice lives in LDS, only weights stream.
+//
+// Why: with every operand fetched as MFMA fragments (kernel above) each wave issues 16 activation
+// loads per 2 weight loads into ONE in-order vmcnt queue, so only ~2 KiB of weights per wave are
+// ever in flight and the CU's vector-memory path is saturated by L2-hot activation fragments
+// (measured: 0.6-0.9 TB/s of weights, independent of L1/L2 residency of x).  Here
+//   * workgroup (nb, sp) = 4 waves = 64 weight rows (one 16-row n-tile per wave) x a range of
+//     1024-byte k-slices; split-K factor S is chosen so that ~320 workgroups exist;
+//   * the x slice [M x 1024 B] is copied ONCE per workgroup into LDS by LDS-DMA in whole rows
+//     (global_load_lds_dwordx4: 1 KiB per wave instruction = one row; rows padded to 1040 B so the
+//     ds_read_b128 fragment reads of 16 rows hit 64 distinct banks);
+//   * each wave issues ALL weight loads of its slice up front (8 chunks x 2 KiB = 64 VGPRs), so the
+//     vmcnt queue holds only weights: 16 KiB per wave in flight;
+//   * x fragments come from LDS (lgkmcnt, independent of vmcnt); v_mfma_scale 16x16x128, unit scales;
+//   * S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to slab[sp][M][N] and a small
+//     second kernel sums the slabs and applies the epilogue.
+template <typename OutT, int MT>
+__global__ __launch_bounds__(256) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
+                                                          int S, int slices_per_wg) {
+  constexpr int XROW = 1040;  // padded LDS row (bytes)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  const int sp = blockIdx.y;
+  const int64_t K = p.K;
+  const int64_t KC = K / 128;              // K % 128 == 0 on this path
+  const int64_t NSL = (KC + 7) / 8;
+  const int64_t sl0 = (int64_t)sp * slices_per_wg;
+  const int64_t sl1 = min(NSL, sl0 + slices_per_wg);
+  const bool tile_ok = n0 < p.N;
+
+  const uint8_t* wp = p.b + min(n0 + r16, p.N - 1) * p.ldb + 16 * q;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t sl = sl0; sl < sl1; ++sl) {
+    const int64_t c0 = sl * 8;
+    const int nch = (int)min((int64_t)8, KC - c0);
+    // ---- all weight loads of this slice (clamped past the end: harmless duplicates)
+    uint4 w0[8], w1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int64_t kb = (c0 + min(c, nch - 1)) * 128;
+      w0[c] = *(const uint4*)(wp + kb);
+      w1[c] = *(const uint4*)(wp + kb + 64);
+    }
+    // ---- x slice -> LDS, one row per wave instruction (lanes past the slice end re-read its start)
+    if (sl != sl0) __syncthreads();  // previous slice's readers are done
+    {
+      const int64_t kx = c0 * 128 + ((lane * 16 < nch * 128) ? lane * 16 : 0);
+#pragma unroll 4
+      for (int r = wave; r < MT * 16; r += 4) {
+        const uint8_t* src = p.a + min((int64_t)r, p.M - 1) * p.lda + kx;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + r * XROW), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- MFMA: weights from registers, activations from LDS
+    if (tile_ok) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < nch) {
+          const i32x8 wf = {(int)w0[c].x, (int)w0[c].y, (int)w0[c].z, (int)w0[c].w,
+                            (int)w1[c].x, (int)w1[c].y, (int)w1[c].z, (int)w1[c].w};
+          const char* xr = smem + r16 * XROW + c * 128 + 16 * q;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const uint4 x0 = *(const uint4*)(xr + t * 16 * XROW);
+            const uint4 x1 = *(const uint4*)(xr + t * 16 * XROW + 64);
+            const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          }
+        }
+      }
+    }
+  }
+  if (!tile_ok) return;
+
+  const int64_t nb = n0 + 4 * q;
+  if (S > 1) {  // fp32 partial tile -> slab[sp][m][n]
+    float* sb = slab + (int64_t)sp * p.M * p.N;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int64_t m = (int64_t)t * 16 + r16;
+      if (m >= p.M) continue;
+      float* o = sb + m * p.N + nb;
+      if (nb + 3 < p.N && (p.N & 3) == 0) {
+        *(f32x4*)o = acc[t];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < p.N) o[r] = acc[t][r];
+      }
+    }
+    return;
+  }
+  float sbv[4], bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t n = min(nb + r, p.N - 1);
+    sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+    bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int64_t m = (int64_t)t * 16 + r16;
+    if (m >= p.M) continue;
+    const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+    OutT* o = (OutT*)p.out + m * p.ldo + nb;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * sav * sbv[r] + bv[r];
+    if (nb + 3 < p.N && (p.ldo & 3) == 0) {
+      *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.N) o[r] = (OutT)v[r];
+    }
+  }
+}
+
+// sum the S split-K slabs and apply the epilogue: one thread per 4 consecutive n
 template <typename OutT>
-static void launch_fp8_gemm(const GemmParams& p, hipStream_t st) {
+__global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p, const float* __restrict__ slab, int S) {
+  const int64_t nq = (p.N + 3) / 4;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= p.M * nq) return;
+  const int64_t m = gid / nq, nb = (gid % nq) * 4;
+  const bool vec = (nb + 3 < p.N) && ((p.N & 3) == 0);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float* src = slab + ((int64_t)s * p.M + m) * p.N + nb;
+    if (vec) {
+      const f32x4 x = *(const f32x4*)src;
+      v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.N) v[r] += src[r];
+    }
+  }
+  const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+  OutT* o = (OutT*)p.out + m * p.ldo + nb;
+  for (int r = 0; r < 4; ++r) {
+    const int64_t n = min(nb + r, p.N - 1);
+    const float sbv = p.sb_row ? p.sb[n] : p.sb[0];
+    const float bv = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+    v[r] = v[r] * sav * sbv + bv;
+  }
+  if (vec && (p.ldo & 3) == 0) {
+    *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+  } else {
+    for (int r = 0; r < 4; ++r)
+      if (nb + r < p.N) o[r] = (OutT)v[r];
+  }
+}
+
+static void xs_plan(int64_t N, int64_t K, int* S, int* spw) {
+  const int64_t nblk = cdiv64(N, 64), nsl = cdiv64(K / 128, 8);
+  int64_t want = cdiv64(320, nblk);
+  if (want < 1) want = 1;
+  if (want > nsl) want = nsl;
+  const int64_t per = cdiv64(nsl, want);
+  *spw = (int)per;
+  *S = (int)cdiv64(nsl, per);
+}
+
+template <typename OutT, int MT>
+static void launch_xs(const GemmParams& p, float* slab, int S, int spw, hipStream_t st) {
+  const size_t lds = (size_t)MT * 16 * 1040;
+  dim3 grid((unsigned)cdiv64(p.N, 64), (unsigned)S);
+  fp8_gemm_xs_kernel<OutT, MT><<<grid, 256, lds, st>>>(p, slab, S, spw);
+  if (S > 1) {
+    const int64_t total = p.M * cdiv64(p.N, 4);
+    fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, slab, S);
+  }
+}
+
+extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M > 128 || M <= 0 || K % 128 != 0) return 0;
+  int S, spw;
+  xs_plan(N, K, &S, &spw);
+  return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+}
+
+template <typename OutT>
+static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
+  if (p.M <= 128 && p.K % 128 == 0 && p.rotate != 3) {  // decode shapes: x-stationary, weights streamed once
+    int S, spw;
+    xs_plan(p.N, p.K, &S, &spw);
+    const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
+    if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {  // no room for slabs: no split-K
+      S = 1;
+      spw = (int)cdiv64(p.K / 128, 8);
+    }
+    float* slab = (float*)workspace;
+    if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st);
+    else if (p.M <= 32) launch_xs<OutT, 2>(p, slab, S, spw, st);
+    else if (p.M <= 64) launch_xs<OutT, 4>(p, slab, S, spw, st);
+    else launch_xs<OutT, 8>(p, slab, S, spw, st);
+    return;
+  }
+  if (p.M <= 128) {  // K % 128 != 0: fragment-streaming kernel
+    if (p.M <= 16) launch_skinny<OutT, 1>(p, st);
+    else if (p.M <= 32) launch_skinny<OutT, 2>(p, st);
+    else if (p.M <= 64) launch_skinny<OutT, 4>(p, st);
+    else launch_skinny<OutT, 8>(p, st);
+    return;
+  }
   const unsigned gx = (unsigned)cdiv64(p.N, 64);
   if (p.M <= 16) fp8_gemm_kernel<OutT, 1><<<dim3(gx, (unsigned)cdiv64(p.M, 16)), 256, 0, st>>>(p);
   else if (p.M <= 32) fp8_gemm_kernel<OutT, 2><<<dim3(gx, (unsigned)cdiv64(p.M, 32)), 256, 0, st>>>(p);
@@ -120,7 +467,7 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st) {
 extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
                            const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t lda,
                            int64_t ldb, int64_t ldo, int scale_a_mode, int scale_b_mode, int out_dtype,
-                           void* stream) {
+                           void* workspace, int64_t workspace_bytes, void* stream) {
   MI_CHECK_ARG(M >= 0 && N >= 0 && K > 0);
   if (M == 0 || N == 0) return MI_OK;
   MI_CHECK_ARG(a && b_nk && scale_a && scale_b && out);
@@ -136,9 +483,14 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b;
   p.bias = bias; p.out = out; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.sa_row = scale_a_mode == MI_SCALE_ROW; p.sb_row = scale_b_mode == MI_SCALE_ROW;
+  {
+    static const int rot_env = [] { const char* e = getenv("MI_GEMM_ROTATE"); return e ? atoi(e) : 1; }();
+    p.rotate = rot_env;
+  }
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == MI_BF16) launch_fp8_gemm<bf16_t>(p, st);
-  else launch_fp8_gemm<f16_t>(p, st);
+  MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
+  if (out_dtype == MI_BF16) launch_fp8_gemm<bf16_t>(p, st, workspace, workspace_bytes);
+  else launch_fp8_gemm<f16_t>(p, st, workspace, workspace_bytes);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -173,6 +173,20 @@ def fp8_quant_per_token(x: torch.Tensor, out: Optional[torch.Tensor] = None,
     return out, scales
 
 
+_GEMM_WS = {}
+
+
+def _gemm_workspace(nbytes: int, device) -> torch.Tensor:
+    """Split-K scratch, one growing buffer per device; stream-ordered use (calls on one stream are
+    serialised, so consecutive GEMMs may share it; grown outside graph capture by the warm-up run)."""
+    key = str(device)
+    buf = _GEMM_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _GEMM_WS[key] = buf
+    return buf
+
+
 def fp8_gemm(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
              out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -190,9 +204,11 @@ def fp8_gemm(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b
     out = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
     if bias is not None:
         assert bias.dtype == out_dtype and bias.numel() == N and bias.is_contiguous()
+    ws_bytes = lib.mi_fp8_gemm_workspace_bytes(M, N, K)
+    ws = _gemm_workspace(ws_bytes, a.device) if ws_bytes else None
     check(lib.mi_fp8_gemm(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(bias), _ptr(out), M, N, K,
                           a.stride(0), b_kn.stride(1), out.stride(0), sa_mode, sb_mode, _DT[out_dtype],
-                          _stream()), "mi_fp8_gemm")
+                          _ptr(ws), ws_bytes if ws is not None else 0, _stream()), "mi_fp8_gemm")
     return out
 
 

@@ -137,7 +137,11 @@ int mi_fp8_quant_per_token(const void* x, void* q, float* scales, int64_t M, int
 int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
                 const void* bias /* nullable, out_dtype */, void* out, int64_t M, int64_t N,
                 int64_t K, int64_t lda, int64_t ldb, int64_t ldo, int scale_a_mode,
-                int scale_b_mode, int out_dtype, void* stream);
+                int scale_b_mode, int out_dtype, void* workspace /* nullable */,
+                int64_t workspace_bytes, void* stream);
+/* bytes of split-K scratch mi_fp8_gemm can use for this shape (0: none needed).  Passing less
+ * (or null) is always correct, only slower for small-N decode shapes. */
+int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* -------------------------------------------------------- int4 weight-only GEMM */
 

@@ -57,4 +57,5 @@ def test_silu_and_mul(dtype):
     x = (torch.randn(65, 2 * 14336, generator=g) * 2).to(dtype)
     out = o_.silu_and_mul(x.to(DEV))
     ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
-    torch.testing.assert_close(out.cpu().float(), oe.silu_and_mul(x).float(), rtol=2 * ulp, atol=1e-6)
+    # two roundings (silu, then the product): allow 2 ulp of the output dtype
+    torch.testing.assert_close(out.cpu().float(), oe.silu_and_mul(x).float(), rtol=4 * ulp, atol=1e-6)
