@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--contiguous", action="store_true", help="contiguous KV slots instead of scattered")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--act-scheme", choices=["static", "dynamic"], default="static",
+                    help="FP8 activation scale: static = serialized FP8 checkpoint with calibrated per-tensor "
+                         "input scales (the reference's own FP8 test model format), dynamic = bf16 checkpoint "
+                         "quantised at load, per-tensor absmax every call")
     ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
     ap.add_argument("--kernel-reps", type=int, default=3, help="passes over all layers for the roofline timing")
     return ap.parse_args()
@@ -198,11 +202,15 @@ def main():
     backend = MiAttnBackend(runner)
     if a.splits:
         backend._choose_splits = lambda bs, tot: a.splits
-    cfg = Fp8Config(is_checkpoint_fp8_serialized=False, activation_scheme="dynamic")
+    static = a.act_scheme == "static"
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=static, activation_scheme=a.act_scheme)
     stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=tp, rank=rank, group=group)
     fb = H.make_decode_batch(runner, backend, B, S, dev, scattered=not a.contiguous, seed=0)
     ids = torch.randint(0, shape.vocab, (B,), device=dev)
     out_ids = torch.empty_like(ids)
+    if static:
+        backend.init_forward_metadata(fb)
+        stack.calibrate_static_input_scales(torch.index_select(stack.embed, 0, ids), fb.positions, fb, backend)
 
     def step():
         hidden = torch.index_select(stack.embed, 0, ids)
@@ -265,7 +273,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), bf16 KV/f32 softmax (attention)",
         "data": "synthetic",
-        "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears (dynamic activation scale), "
+        "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears ({a.act_scheme} activation scale), "
                                f"bf16 paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,

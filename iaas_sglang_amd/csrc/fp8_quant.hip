@@ -35,8 +35,8 @@ __device__ __forceinline__ uint2 quant8(const float (&f)[8], float inv) {
 
 // ------------------------------------------------------------------ per tensor
 template <typename T>
-__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, float* __restrict__ scale,
-                                                     int64_t M, int64_t K, int64_t ldx, int raw) {
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                     int64_t M, int64_t K, int64_t ldx) {
   __shared__ float red[4];
   const int64_t vec_per_row = K / 8;
   const int64_t total = M * vec_per_row;
@@ -51,21 +51,39 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, fl
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    // non-negative floats order like their bit patterns
-    atomicMax((unsigned int*)scale, __float_as_uint(raw ? mx : mx / FP8_MAX));
-  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void quant_tensor_kernel(const T* __restrict__ x, uint8_t* __restrict__ q,
-                                                           const float* __restrict__ scale, int64_t M,
-                                                           int64_t K, int64_t ldx, int raw) {
-  const float s = *scale;
-  // raw: *scale holds amax and the multiplier is 448/max(amax,1e-12) (input_to_float8,
-  // quantization/fp8_utils.py:314-325); else *scale is the dequant scale and we multiply by 1/scale
-  const float inv = raw ? FP8_MAX / fmaxf(s, 1e-12f) : (s > 0.f ? 1.0f / s : 0.f);
+                                                           float* __restrict__ scale, int64_t M,
+                                                           int64_t K, int64_t ldx, int mode,
+                                                           const float* __restrict__ partial, int npartial) {
+  // mode 1 (static): *scale is given.  modes 0/2 (dynamic): every block reduces the per-block maxima
+  // of absmax_kernel (<= 2048 floats, L2-hot) to the tensor amax; block 0 publishes the scale.
+  //   0: scale = amax/448, multiplier 1/scale                    (per_tensor_quant_fp8.cu:42,54)
+  //   2: multiplier 448/max(amax,1e-12), scale = 1/multiplier    (input_to_float8, fp8_utils.py:314-325)
+  __shared__ float red[4];
+  float s, inv;
+  if (mode == 1) {
+    s = *scale;
+    inv = s > 0.f ? 1.0f / s : 0.f;
+  } else {
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < npartial; i += 256) mx = fmaxf(mx, partial[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (mode == 0) {
+      s = mx / FP8_MAX;
+      inv = s > 0.f ? 1.0f / s : 0.f;
+    } else {
+      inv = FP8_MAX / fmaxf(mx, 1e-12f);
+      s = 1.0f / inv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale = s;
+  }
   const int64_t vec_per_row = K / 8;
   const int64_t total = M * vec_per_row;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -76,10 +94,18 @@ __global__ __launch_bounds__(256) void quant_tensor_kernel(const T* __restrict__
   }
 }
 
-// weight mode epilogue: amax -> dequant scale 1 / (448 / max(amax, 1e-12))
-__global__ void amax_to_inv_scale_kernel(float* scale) {
-  const float mult = FP8_MAX / fmaxf(*scale, 1e-12f);
-  *scale = 1.0f / mult;
+// scratch for the per-block maxima: a __device__ array of the code object (no allocation, graph
+// safe).  Calls are stream-ordered; two calls on DIFFERENT streams must not overlap, which holds for
+// the single-stream model runner this library plugs into.
+__device__ float g_absmax_partial[2048];
+static float* partial_buffer() {
+  static float* ptr = nullptr;
+  if (!ptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_absmax_partial)) != hipSuccess) return nullptr;
+    ptr = (float*)p;
+  }
+  return ptr;
 }
 
 extern "C" int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int64_t M, int64_t K,
@@ -100,23 +126,28 @@ extern "C" int mi_fp8_quant_per_tensor(const void* x, void* q, float* scale, int
   MI_CHECK_ARG((((uintptr_t)x & 15) | ((uintptr_t)q & 7)) == 0);
   const int64_t total = M * (K / 8);
   unsigned blocks = (unsigned)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
-  const int raw = is_static == 2;
+  float* partial = nullptr;
   if (is_static != 1) {
-    if (hipMemsetAsync(scale, 0, sizeof(float), st) != hipSuccess)
-      MI_FAIL(MI_ERR_LAUNCH, "mi_fp8_quant_per_tensor: memset failed");
-    if (dtype == MI_BF16) absmax_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, scale, M, K, ldx, raw);
-    else absmax_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, scale, M, K, ldx, raw);
+    partial = partial_buffer();
+    if (!partial) MI_FAIL(MI_ERR_LAUNCH, "mi_fp8_quant_per_tensor: reduction scratch symbol not found");
+    // fewer, fatter blocks for the max pass: 8 vectors per thread
+    unsigned ab = (unsigned)(cdiv64(total, 256 * 8) < 2048 ? cdiv64(total, 256 * 8) : 2048);
+    if (ab < 1) ab = 1;
+    if (dtype == MI_BF16) absmax_kernel<bf16_t><<<ab, 256, 0, st>>>((const bf16_t*)x, partial, M, K, ldx);
+    else absmax_kernel<f16_t><<<ab, 256, 0, st>>>((const f16_t*)x, partial, M, K, ldx);
     MI_CHECK_LAUNCH();
+    if (dtype == MI_BF16)
+      quant_tensor_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (uint8_t*)q, scale, M, K, ldx, is_static, partial, (int)ab);
+    else
+      quant_tensor_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (uint8_t*)q, scale, M, K, ldx, is_static, partial, (int)ab);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
   }
   if (dtype == MI_BF16)
-    quant_tensor_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (uint8_t*)q, scale, M, K, ldx, raw);
+    quant_tensor_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (uint8_t*)q, scale, M, K, ldx, 1, nullptr, 0);
   else
-    quant_tensor_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (uint8_t*)q, scale, M, K, ldx, raw);
+    quant_tensor_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (uint8_t*)q, scale, M, K, ldx, 1, nullptr, 0);
   MI_CHECK_LAUNCH();
-  if (raw) {
-    amax_to_inv_scale_kernel<<<1, 1, 0, st>>>(scale);
-    MI_CHECK_LAUNCH();
-  }
   return MI_OK;
 }
 

@@ -91,7 +91,13 @@ class Linear(torch.nn.Module):
         quant_method.create_weights(self, in_features, out_partition_sizes, in_features, sum(out_partition_sizes),
                                     params_dtype, weight_loader=None)
 
+    calibrating = False   # class-wide switch used by LlamaStack.calibrate_static_input_scales
+
     def forward(self, x):
+        if Linear.calibrating and getattr(self, "input_scale", None) is not None:
+            # one-off calibration of a static per-tensor activation scale (what an FP8 checkpoint ships):
+            # scale = absmax / 448, per_tensor_quant_fp8.cu:42 -- torch here, never on the timed path
+            self.input_scale.data.copy_((x.float().abs().max() / 448.0).reshape(1))
         return self.quant_method.apply(self, x, self.bias)
 
 
@@ -169,12 +175,16 @@ class LlamaStack:
     def _init_linear(lin, dummy):
         """Fill whatever checkpoint-layout parameters the method created with synthetic data."""
         names = dict(lin.named_parameters())
-        if "weight" in names:                      # fp8 from a bf16 checkpoint: plain weight
+        if "weight" in names:
             w = names["weight"]
-            if w.dtype in (torch.bfloat16, torch.float16):
+            if w.dtype in (torch.bfloat16, torch.float16):   # fp8 from a bf16 checkpoint: plain weight
                 w.data.copy_(dummy(*w.shape))
-            else:
-                raise NotImplementedError("serialized-fp8 synthetic init is done by the tests")
+            else:                                            # serialized FP8 checkpoint: fp8 weight + scales
+                qw, ws = ops.fp8_quant_per_tensor(dummy(*w.shape), weight_mode=True)
+                w.data.copy_(qw)
+                names["weight_scale"].data.copy_(ws.expand_as(names["weight_scale"]))
+                if names.get("input_scale") is not None:
+                    names["input_scale"].data.fill_(1.0)     # calibrated later
         if "qweight" in names:                     # int4: random nibbles, small scales (SURVEY 8d)
             dev = names["qweight"].device
             g = torch.Generator(device=dev).manual_seed(1234)
@@ -188,6 +198,15 @@ class LlamaStack:
 
     def _all_reduce(self, x):
         return tensor_model_parallel_all_reduce(x, self.tp, self.group)   # RowParallelLinear (linear.py:1376-1378)
+
+    def calibrate_static_input_scales(self, hidden, positions, fb, backend):
+        """Give every static-activation linear a realistic `input_scale` (amax/448 of one forward pass),
+        standing in for the calibrated scales a serialized FP8 checkpoint carries."""
+        Linear.calibrating = True
+        try:
+            self.forward(hidden, positions, fb, backend)
+        finally:
+            Linear.calibrating = False
 
     def forward(self, hidden, positions, fb, backend):
         """hidden [T, H] -> logits [T, vocab]; follows llama.py:245-268 with the fused add+norm form."""

@@ -116,7 +116,8 @@ int mi_merge_state(const void* o_a, const float* lse_a, const void* o_b, const f
  *   0 dynamic activation : scale[0] = absmax(x)/448 (written), q = sat(x * (1/scale))
  *   1 static             : scale given,                         q = sat(x * (1/scale))
  *   2 dynamic weight     : q = sat(x * (448/max(absmax,1e-12))), scale[0] = 1/(448/amax) (written)
- *   In modes 0/2 the call itself resets `scale` on the stream before reducing into it.
+ *   Modes 0/2 are two launches (per-block maxima into an internal 8-KB scratch, then reduce +
+ *   quantise; no atomics, no memset); calls must be stream-ordered with respect to each other.
  * replaces: 0/1 sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:96-123
  * (and vllm ops.scaled_fp8_quant per-tensor as called at fp8_utils.py:669-674);
  * 2 input_to_float8, quantization/fp8_utils.py:310-326 (weights of bf16 checkpoints, fp8.py:359). */

@@ -24,7 +24,7 @@ def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_len
             x = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps)
         else:
             x, residual = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps, residual)
-        qkv = oq.fp8_linear(x, W["qkv_w"], W["qkv_s"])
+        qkv = oq.fp8_linear(x, W["qkv_w"], W["qkv_s"], W.get("qkv_i"))
         q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
         q, k = oe.rope_neox(positions, q.contiguous(), k.contiguous(), cache, D)
         k3, v3 = k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D)
@@ -32,40 +32,46 @@ def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_len
             a = oa.forward_decode(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, loc, Hq, Hkv, D ** -0.5)
         else:
             a = oa.forward_extend(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, pre, ext, loc, Hq, Hkv, D ** -0.5)
-        hidden = oq.fp8_linear(a, W["o_w"], W["o_s"])
+        hidden = oq.fp8_linear(a, W["o_w"], W["o_s"], W.get("o_i"))
         x, residual = oe.rmsnorm(hidden, W["post_norm"], shape.rms_eps, residual)
-        gu = oq.fp8_linear(x, W["gu_w"], W["gu_s"])
-        hidden = oq.fp8_linear(oe.silu_and_mul(gu), W["down_w"], W["down_s"])
+        gu = oq.fp8_linear(x, W["gu_w"], W["gu_s"], W.get("gu_i"))
+        hidden = oq.fp8_linear(oe.silu_and_mul(gu), W["down_w"], W["down_s"], W.get("down_i"))
     x, _ = oe.rmsnorm(hidden, stack_w["final_norm"], shape.rms_eps, residual)
     return (x.float() @ stack_w["lm_head"].float().t())
 
 
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
 @pytest.mark.parametrize("weight_range,tol", [(1e-3, 1e-3), (0.05, 5e-2)])
-def test_tiny_llama_fp8_extend_then_decode(weight_range, tol):
+def test_tiny_llama_fp8_extend_then_decode(weight_range, tol, scheme):
     from iaas_sglang_amd import harness as H
     from iaas_sglang_amd.attention_backend import MiAttnBackend
     from iaas_sglang_amd.quantization import Fp8Config
 
     shape, dtype = H.TINY, torch.bfloat16
-    cfg = Fp8Config(is_checkpoint_fp8_serialized=False, activation_scheme="dynamic")
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=(scheme == "static"), activation_scheme=scheme)
     runner = H.make_runner(shape, max_reqs=8, ctx=128, pool_tokens=600, dtype=dtype, device=DEV)
     backend = MiAttnBackend(runner)
     stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, DEV, weight_range=weight_range,
                          weights_cpu_seeded=True)
-    # the quantised weights as the oracle sees them ([K,N] fp8 view + scale), copied off the device
-    W = {"layers": [], "final_norm": stack.final_norm.cpu(), "lm_head": stack.lm_head.cpu()}
-    for L in stack.layers:
-        W["layers"].append({"input_norm": L.input_norm.cpu(), "post_norm": L.post_norm.cpu(),
-                            "qkv_w": L.qkv.weight.cpu(), "qkv_s": L.qkv.weight_scale.cpu(),
-                            "o_w": L.o.weight.cpu(), "o_s": L.o.weight_scale.cpu(),
-                            "gu_w": L.gate_up.weight.cpu(), "gu_s": L.gate_up.weight_scale.cpu(),
-                            "down_w": L.down.weight.cpu(), "down_s": L.down.weight_scale.cpu()})
     g = torch.Generator().manual_seed(0)
     prefix, extend = [0, 0, 0], [37, 5, 64]
     fb = H.make_extend_batch(runner, backend, prefix, extend, DEV, seed=1)
     E = sum(extend)
     hidden = torch.randn(E, shape.hidden, generator=g).to(dtype)
     backend.init_forward_metadata(fb)
+    if scheme == "static":   # calibrated per-tensor input scales, as a serialized FP8 checkpoint carries
+        stack.calibrate_static_input_scales(hidden.to(DEV), fb.positions, fb, backend)
+        for b in runner.token_to_kv_pool.k_buffer + runner.token_to_kv_pool.v_buffer:
+            b.zero_()
+    # the quantised weights as the oracle sees them ([K,N] fp8 view + scales), copied off the device
+    W = {"layers": [], "final_norm": stack.final_norm.cpu(), "lm_head": stack.lm_head.cpu()}
+    for L in stack.layers:
+        d = {"input_norm": L.input_norm.cpu(), "post_norm": L.post_norm.cpu()}
+        for key, lin in (("qkv", L.qkv), ("o", L.o), ("gu", L.gate_up), ("down", L.down)):
+            d[key + "_w"], d[key + "_s"] = lin.weight.cpu(), lin.weight_scale.cpu()
+            if scheme == "static":
+                d[key + "_i"] = lin.input_scale.cpu()
+        W["layers"].append(d)
     logits = stack.forward(hidden.to(DEV), fb.positions, fb, backend)
     kc = [torch.zeros_like(b).cpu() for b in runner.token_to_kv_pool.k_buffer]
     vc = [torch.zeros_like(b).cpu() for b in runner.token_to_kv_pool.v_buffer]
