@@ -244,36 +244,40 @@ static void launch_skinny(const GemmParams& p, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Decode-shaped GEMM v3 ("x-stationary"): the activation slice lives in LDS, only weights stream.
+// Decode-shaped GEMM ("x-stationary"): activations live in LDS, only weights stream through VGPRs.
 //
 // Why: with every operand fetched as MFMA fragments (kernel above) each wave issues 16 activation
 // loads per 2 weight loads into ONE in-order vmcnt queue, so only ~2 KiB of weights per wave are
 // ever in flight and the CU's vector-memory path is saturated by L2-hot activation fragments
-// (measured: 0.6-0.9 TB/s of weights, independent of L1/L2 residency of x).  Here
-//   * workgroup (nb, sp) = 4 waves = 64 weight rows (one 16-row n-tile per wave) x a range of
-//     1024-byte k-slices; split-K factor S is chosen so that ~320 workgroups exist;
-//   * the x slice [M x 1024 B] is copied ONCE per workgroup into LDS by LDS-DMA in whole rows
-//     (global_load_lds_dwordx4: 1 KiB per wave instruction = one row; rows padded to 1040 B so the
-//     ds_read_b128 fragment reads of 16 rows hit 64 distinct banks);
-//   * each wave issues ALL weight loads of its slice up front (8 chunks x 2 KiB = 64 VGPRs), so the
-//     vmcnt queue holds only weights: 16 KiB per wave in flight;
-//   * x fragments come from LDS (lgkmcnt, independent of vmcnt); v_mfma_scale 16x16x128, unit scales;
-//   * S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to slab[sp][M][N] and a small
-//     second kernel sums the slabs and applies the epilogue.
-template <typename OutT, int MT>
-__global__ __launch_bounds__(256) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
-                                                          int S, int slices_per_wg) {
-  constexpr int XROW = 1040;  // padded LDS row (bytes)
+// (measured 0.6-0.9 TB/s of weights, independent of L1/L2 residency of x).  Here
+//   * workgroup (nb, sp) = NWV waves = NWV 16-row weight tiles (one per wave) x a range of 512-byte
+//     k-phases; split-K factor S is chosen so that roughly 320 workgroups exist (small N), S = 1 when
+//     N alone provides them (then no slab traffic);
+//   * per phase the x block [M x 512 B] is copied into one of TWO LDS buffers by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave instruction = two whole 512-B row segments) while the
+//     previous phase computes; rows are unpadded (the DMA needs a lane-linear image) and the 16-byte
+//     slot index is XOR-swizzled with (row & 15) on the SOURCE address, so the ds_read_b128 fragment
+//     reads of 16 rows hit 16 distinct 4-bank groups;
+//   * each wave keeps two phases of weight fragments in registers (4 chunks x 2 KiB x 2): the vmcnt
+//     queue holds only weights + the DMA;
+//   * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the unscaled fp8 rate);
+//   * one barrier per phase; S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to
+//     slab[sp][M][N], summed by fp8_gemm_reduce_kernel.
+template <typename OutT, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
+                                                               int S, int phases_per_wg) {
+  constexpr int PW = 512;               // phase width (bytes of K)
+  constexpr int ROWS = MT * 16;
+  constexpr int BUF = ROWS * PW;        // one LDS buffer
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  const int64_t n0 = ((int64_t)blockIdx.x * NWV + wave) * 16;
   const int sp = blockIdx.y;
-  const int64_t K = p.K;
-  const int64_t KC = K / 128;              // K % 128 == 0 on this path
-  const int64_t NSL = (KC + 7) / 8;
-  const int64_t sl0 = (int64_t)sp * slices_per_wg;
-  const int64_t sl1 = min(NSL, sl0 + slices_per_wg);
+  const int64_t KC = p.K / 128;         // K % 128 == 0 on this path
+  const int64_t NPH = (KC + 3) / 4;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
   const bool tile_ok = n0 < p.N;
 
   const uint8_t* wp = p.b + min(n0 + r16, p.N - 1) * p.ldb + 16 * q;
@@ -281,49 +285,84 @@ __global__ __launch_bounds__(256) void fp8_gemm_xs_kernel(const GemmParams p, fl
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t sl = sl0; sl < sl1; ++sl) {
-    const int64_t c0 = sl * 8;
-    const int nch = (int)min((int64_t)8, KC - c0);
-    // ---- all weight loads of this slice (clamped past the end: harmless duplicates)
-    uint4 w0[8], w1[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int64_t kb = (c0 + min(c, nch - 1)) * 128;
-      w0[c] = *(const uint4*)(wp + kb);
-      w1[c] = *(const uint4*)(wp + kb + 64);
-    }
-    // ---- x slice -> LDS, one row per wave instruction (lanes past the slice end re-read its start)
-    if (sl != sl0) __syncthreads();  // previous slice's readers are done
-    {
-      const int64_t kx = c0 * 128 + ((lane * 16 < nch * 128) ? lane * 16 : 0);
-#pragma unroll 4
-      for (int r = wave; r < MT * 16; r += 4) {
-        const uint8_t* src = p.a + min((int64_t)r, p.M - 1) * p.lda + kx;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + r * XROW), 16, 0, 0);
-      }
-    }
+  // DMA geometry: lane L of a wave instruction covers row (2*i + (L>>5)), LDS slot (L&31);
+  // the global source slot is swizzled: slot ^ (row & 15)
+  const int drow = lane >> 5, dslot = lane & 31;
+
+#define XS_STAGE(ph_, buf_)                                                                        \
+  {                                                                                                \
+    const int64_t kb_ = (int64_t)(ph_) * PW;                                                       \
+    const int nslot_ = (int)min((int64_t)32, (p.K - kb_) / 16);                                    \
+    for (int rr = wave * 2; rr < ROWS; rr += NWV * 2) {                                            \
+      const int row_ = rr + drow;                                                                  \
+      int sslot_ = dslot ^ (row_ & 15);                                                            \
+      sslot_ = sslot_ < nslot_ ? sslot_ : 0;                                                       \
+      const uint8_t* src_ = p.a + min((int64_t)row_, p.M - 1) * p.lda + kb_ + sslot_ * 16;         \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,        \
+                                       (__attribute__((address_space(3))) void*)(smem + (buf_) * BUF + rr * PW), 16, 0, 0); \
+    }                                                                                              \
+  }
+#define XS_WLOAD(W0, W1, ph_)                                                   \
+  {                                                                             \
+    const int64_t c0_ = (int64_t)(ph_) * 4;                                     \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                             \
+      const int64_t kb_ = min(c0_ + c, KC - 1) * 128;                           \
+      W0[c] = *(const uint4*)(wp + kb_);                                        \
+      W1[c] = *(const uint4*)(wp + kb_ + 64);                                   \
+    }                                                                           \
+  }
+#define XS_MMA(W0, W1, ph_, buf_)                                                                          \
+  if (tile_ok) {                                                                                           \
+    const int nch_ = (int)min((int64_t)4, KC - (int64_t)(ph_) * 4);                                        \
+    const char* xb_ = smem + (buf_) * BUF + r16 * PW;                                                      \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                        \
+      if (c < nch_) {                                                                                      \
+        const i32x8 wf_ = {(int)W0[c].x, (int)W0[c].y, (int)W0[c].z, (int)W0[c].w,                         \
+                           (int)W1[c].x, (int)W1[c].y, (int)W1[c].z, (int)W1[c].w};                        \
+        const int o0_ = ((c * 8 + q) ^ r16) * 16, o1_ = ((c * 8 + 4 + q) ^ r16) * 16;                      \
+        _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                   \
+          const uint4 x0_ = *(const uint4*)(xb_ + t * 16 * PW + o0_);                                      \
+          const uint4 x1_ = *(const uint4*)(xb_ + t * 16 * PW + o1_);                                      \
+          const i32x8 xf_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w,                               \
+                             (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w};                              \
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf_, xf_, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  uint4 wa0[4], wa1[4], wb0[4], wb1[4];
+  if (ph0 < ph1) {
+    XS_WLOAD(wa0, wa1, ph0);
+    XS_STAGE(ph0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- MFMA: weights from registers, activations from LDS
-    if (tile_ok) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (c < nch) {
-          const i32x8 wf = {(int)w0[c].x, (int)w0[c].y, (int)w0[c].z, (int)w0[c].w,
-                            (int)w1[c].x, (int)w1[c].y, (int)w1[c].z, (int)w1[c].w};
-          const char* xr = smem + r16 * XROW + c * 128 + 16 * q;
-#pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            const uint4 x0 = *(const uint4*)(xr + t * 16 * XROW);
-            const uint4 x1 = *(const uint4*)(xr + t * 16 * XROW + 64);
-            const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-          }
-        }
+    for (int64_t ph = ph0; ph < ph1; ph += 2) {
+      // ---- even phase: compute (A regs, buffer 0) while phase ph+1 lands (B regs, buffer 1)
+      const bool has1 = ph + 1 < ph1;
+      if (has1) {
+        XS_WLOAD(wb0, wb1, ph + 1);
+        XS_STAGE(ph + 1, 1);
       }
+      XS_MMA(wa0, wa1, ph, 0);
+      if (!has1) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // ---- odd phase
+      const bool has2 = ph + 2 < ph1;
+      if (has2) {
+        XS_WLOAD(wa0, wa1, ph + 2);
+        XS_STAGE(ph + 2, 0);
+      }
+      XS_MMA(wb0, wb1, ph + 1, 1);
+      if (!has2) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
+#undef XS_STAGE
+#undef XS_WLOAD
+#undef XS_MMA
   if (!tile_ok) return;
 
   const int64_t nb = n0 + 4 * q;
@@ -405,21 +444,26 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
   }
 }
 
-static void xs_plan(int64_t N, int64_t K, int* S, int* spw) {
-  const int64_t nblk = cdiv64(N, 64), nsl = cdiv64(K / 128, 8);
-  int64_t want = cdiv64(320, nblk);
+// waves per workgroup: 8 when N alone yields >= ~200 workgroups of 128 rows, else 4
+static int xs_waves(int64_t N) { return cdiv64(N, 128) >= 200 ? 8 : 4; }
+
+static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
+  const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 4);
+  int64_t want = nblk >= 200 ? 1 : cdiv64(320, nblk);
   if (want < 1) want = 1;
-  if (want > nsl) want = nsl;
-  const int64_t per = cdiv64(nsl, want);
-  *spw = (int)per;
-  *S = (int)cdiv64(nsl, per);
+  if (want > nph) want = nph;
+  const int64_t per = cdiv64(nph, want);
+  *ppw = (int)per;
+  *S = (int)cdiv64(nph, per);
 }
 
 template <typename OutT, int MT>
-static void launch_xs(const GemmParams& p, float* slab, int S, int spw, hipStream_t st) {
-  const size_t lds = (size_t)MT * 16 * 1040;
-  dim3 grid((unsigned)cdiv64(p.N, 64), (unsigned)S);
-  fp8_gemm_xs_kernel<OutT, MT><<<grid, 256, lds, st>>>(p, slab, S, spw);
+static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st) {
+  const size_t lds = (size_t)2 * MT * 16 * 512;
+  const int nw = xs_waves(p.N);
+  dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
+  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8><<<grid, 512, lds, st>>>(p, slab, S, ppw);
+  else fp8_gemm_xs_kernel<OutT, MT, 4><<<grid, 256, lds, st>>>(p, slab, S, ppw);
   if (S > 1) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, slab, S);
@@ -441,7 +485,7 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
     if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {  // no room for slabs: no split-K
       S = 1;
-      spw = (int)cdiv64(p.K / 128, 8);
+      spw = (int)cdiv64(p.K / 128, 4);
     }
     float* slab = (float*)workspace;
     if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st);

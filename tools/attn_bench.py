@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of mi_decode_attn at the BASELINE shape (B=128, S=2048, Hq=32, Hkv=8, D=128).
+Cycles over several layer-sized pools so the 256 MB Infinity Cache cannot help.  Not a test."""
+import math
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iaas_sglang_amd import ops  # noqa: E402
+
+dev = "cuda"
+B = int(os.environ.get("B", "128")); S = int(os.environ.get("S", "2048"))
+Hq, Hkv, D = int(os.environ.get("HQ", "32")), int(os.environ.get("HKV", "8")), 128
+npool = int(os.environ.get("NPOOL", "6"))
+contig = os.environ.get("CONTIG", "0") == "1"
+slots = B * S + 1
+pools = [(torch.randn(slots, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16),
+          torch.randn(slots, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16)) for _ in range(npool)]
+q = torch.randn(B, Hq, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+o = torch.empty_like(q)
+g = torch.Generator(device=dev).manual_seed(0)
+idx = (torch.arange(B * S, device=dev) if contig else torch.randperm(B * S, device=dev, generator=g)).to(torch.int32) + 1
+sl = torch.full((B,), S, dtype=torch.int64, device=dev)
+indptr = ops.kv_indptr(sl)
+abytes = 2 * B * S * Hkv * D * 2 + 2 * B * Hq * D * 2 + 4 * B * S
+for ns in [int(x) for x in os.environ.get("SPLITS", "1,2,4,8").split(",")]:
+    ws = torch.empty(max(1, ops.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=dev)
+    for k, v in pools:
+        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 4
+    e0.record()
+    for _ in range(reps):
+        for k, v in pools:
+            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws)
+    e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * npool)
+    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} contig={int(contig)} splits={ns} W={os.environ.get('MI_DECODE_W','auto')}: "
+          f"{us:8.1f} us  {abytes/us/1e3:7.1f} GB/s", flush=True)
