@@ -16,6 +16,7 @@
 //                                                        row by DPP row_newbcast
 // HBM-bound: algorithmic bytes = 2 * tokens * Hkv * D * sizeof(T) (+ indices, q, o).
 #include "common.h"
+#include <stdlib.h>
 
 struct DecodeParams {
   const void* q;
@@ -34,6 +35,17 @@ struct DecodeParams {
 
 #define RESCALE_THR 8.0f
 
+// 16-byte global load; NT = non-temporal (streamed-once KV rows should not displace q / indices / partials)
+typedef __attribute__((ext_vector_type(4))) uint32_t ldg_u32x4;
+template <bool NT> __device__ __forceinline__ uint4 ldg16(const void* p) {
+  if constexpr (NT) {
+    const ldg_u32x4 v = __builtin_nontemporal_load((const ldg_u32x4*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *(const uint4*)p;
+  }
+}
+
 template <int N> struct IntC { static constexpr int value = N; };
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -42,7 +54,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
-template <typename T, int D, int G, int W>
+template <typename T, int D, int G, int W, bool NT>
 __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams p) {
   constexpr int KS = D / 32;       // MFMA k-steps over the head dim
   constexpr int LPT = D / 8;       // lanes per V token row (16 B per lane)
@@ -120,9 +132,9 @@ __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams 
   auto load_tile = [&](Tile& t, int32_t ik, const int32_t (&iv)[NLOAD]) {
     const T* kp = kb + (int64_t)ik * p.stride_k_slot;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) t.kf[ks] = __builtin_bit_cast(vec8, *(const uint4*)(kp + ks * 32));
+    for (int ks = 0; ks < KS; ++ks) t.kf[ks] = __builtin_bit_cast(vec8, ldg16<NT>(kp + ks * 32));
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) t.vv[i] = *(const uint4*)(vb + (int64_t)iv[i] * p.stride_v_slot);
+    for (int i = 0; i < NLOAD; ++i) t.vv[i] = ldg16<NT>(vb + (int64_t)iv[i] * p.stride_v_slot);
   };
 
   auto compute = [&](const Tile& t, int32_t t0) {
@@ -296,16 +308,26 @@ extern "C" int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_h
   return batch * num_q_heads * num_splits * (v_head_dim + 2) * (int64_t)sizeof(float);
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 template <typename T, int D, int G, int W>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
+  static const int nt = env_int("MI_DECODE_NT", 0);
   dim3 grid((unsigned)p.num_splits, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)batch);
-  decode_attn_kernel<T, D, G, W><<<grid, W * 64, 0, st>>>(p);
+  if (nt) decode_attn_kernel<T, D, G, W, true><<<grid, W * 64, 0, st>>>(p);
+  else decode_attn_kernel<T, D, G, W, false><<<grid, W * 64, 0, st>>>(p);
 }
 
 template <typename T, int D, int G>
 static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st) {
+  static const int wenv = env_int("MI_DECODE_W", 0);
   const int h = p.num_kv_heads;
-  if (h % 8 == 0) launch_decode<T, D, G, 8>(p, batch, st);
+  if (wenv == 4 && h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
+  else if (wenv == 2 && h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
+  else if (h % 8 == 0) launch_decode<T, D, G, 8>(p, batch, st);
   else if (h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
   else if (h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
   else launch_decode<T, D, G, 1>(p, batch, st);
