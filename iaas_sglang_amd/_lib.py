@@ -37,6 +37,16 @@ SIGNATURES = {
     "mi_fp8_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "mi_w4_repack": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_ar_shared_bytes": (_i64, [_i64]),
+    "mi_ar_alloc_shared": (_int, [_i64, C.POINTER(C.c_void_p)]),
+    "mi_ar_free_shared": (_int, [_p]),
+    "mi_ar_ipc_get": (_int, [_p, _p]),
+    "mi_ar_ipc_open": (_int, [_p, C.POINTER(C.c_void_p)]),
+    "mi_ar_ipc_close": (_int, [_p]),
+    "mi_ar_create": (_p, [C.POINTER(C.c_void_p), _i64, _int, _int]),
+    "mi_ar_destroy": (_int, [_p]),
+    "mi_ar_error": (_int, [_p]),
+    "mi_ar_all_reduce": (_int, [_p, _p, _p, _i64, _int, _p]),
     "mi_rmsnorm": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
     "mi_rope_neox": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_silu_and_mul": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p]),

@@ -1,0 +1,98 @@
+"""`CustomAllreduce`: native xGMI all-reduce for the TP row-parallel linears.
+
+Mirrors the reference wrapper (python/sglang/srt/distributed/device_communicators/
+custom_all_reduce.py:147-151 sizes, :360-385 handle exchange, :414-435 should_custom_ar,
+:446-497 eager staging) on top of the C ABI `mi_ar_*` (csrc/allreduce.hip).  IPC handles are
+exchanged through a CPU (gloo) process group with all_gather_object, exactly like the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from ._lib import MI_BF16, MI_F32, MI_FP16, MiHotpathError, check, lib
+
+_DT = {torch.bfloat16: MI_BF16, torch.float16: MI_FP16, torch.float32: MI_F32}
+
+
+class CustomAllreduce:
+    _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]          # custom_all_reduce.py:147
+
+    def __init__(self, cpu_group: dist.ProcessGroup, device: torch.device, max_size: int = 8 * 1024 * 1024):
+        self.disabled = True
+        self.group = cpu_group
+        self.rank = dist.get_rank(group=cpu_group)
+        self.world_size = dist.get_world_size(group=cpu_group)
+        self.device = torch.device(device)
+        self.max_size = max_size
+        self._ctx = None
+        self._own = C.c_void_p()
+        self._peers: List[Optional[int]] = []
+        if self.world_size == 1 or self.world_size not in self._SUPPORTED_WORLD_SIZES:
+            return
+        torch.cuda.set_device(self.device)
+        nbytes = lib.mi_ar_shared_bytes(max_size)
+        check(lib.mi_ar_alloc_shared(nbytes, C.byref(self._own)), "mi_ar_alloc_shared")
+        handle = (C.c_char * 64)()
+        check(lib.mi_ar_ipc_get(self._own, handle), "mi_ar_ipc_get")
+        handles: List[Optional[bytes]] = [None] * self.world_size
+        dist.all_gather_object(handles, bytes(handle.raw), group=cpu_group)
+        ptrs = (C.c_void_p * self.world_size)()
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs[r] = self._own.value
+                self._peers.append(None)
+            else:
+                p = C.c_void_p()
+                check(lib.mi_ar_ipc_open(C.create_string_buffer(h, 64), C.byref(p)), "mi_ar_ipc_open")
+                ptrs[r] = p.value
+                self._peers.append(p.value)
+        self._ctx = lib.mi_ar_create(ptrs, max_size, self.rank, self.world_size)
+        if not self._ctx:
+            raise MiHotpathError(f"mi_ar_create failed: {lib.mi_last_error().decode()}")
+        dist.barrier(group=cpu_group)               # every rank has mapped every buffer
+        self.disabled = False
+
+    def should_custom_ar(self, inp: torch.Tensor) -> bool:
+        """custom_all_reduce.py:414-435: 16-byte multiple, contiguous, within the registered size."""
+        if self.disabled:
+            return False
+        nbytes = inp.numel() * inp.element_size()
+        return (nbytes % 16 == 0 and inp.is_contiguous() and nbytes <= self.max_size and inp.dtype in _DT)
+
+    def all_reduce(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(inp) if out is None else out
+        check(lib.mi_ar_all_reduce(self._ctx, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                                   _DT[inp.dtype], torch.cuda.current_stream().cuda_stream), "mi_ar_all_reduce")
+        return out
+
+    def custom_all_reduce(self, inp: torch.Tensor) -> Optional[torch.Tensor]:
+        """None means: fall through to RCCL (parallel_state.py:495-500)."""
+        return self.all_reduce(inp) if self.should_custom_ar(inp) else None
+
+    def timed_out(self) -> bool:
+        return (not self.disabled) and lib.mi_ar_error(self._ctx) != 0
+
+    def close(self):
+        if self._ctx:
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            lib.mi_ar_destroy(self._ctx)
+            self._ctx = None
+            for p in self._peers:
+                if p is not None:
+                    lib.mi_ar_ipc_close(p)
+            dist.barrier(group=self.group)
+            lib.mi_ar_free_shared(self._own)
+            self.disabled = True
+
+    def __del__(self):
+        try:
+            if self._ctx:
+                lib.mi_ar_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass

@@ -18,8 +18,15 @@ def shard_sizes(num_heads: int, num_kv_heads: int, intermediate: int, vocab: int
                 vocab=vocab // tp)
 
 
-def tensor_model_parallel_all_reduce(x: torch.Tensor, tp: int, group: Optional[dist.ProcessGroup]) -> torch.Tensor:
+def tensor_model_parallel_all_reduce(x: torch.Tensor, tp: int, group: Optional[dist.ProcessGroup],
+                                     custom_ar=None) -> torch.Tensor:
+    """GroupCoordinator.all_reduce's dispatch (distributed/parallel_state.py:426-500): the native xGMI
+    kernel out of place when it applies, otherwise RCCL in place."""
     if tp > 1:
+        if custom_ar is not None:
+            out = custom_ar.custom_all_reduce(x)
+            if out is not None:
+                return out
         dist.all_reduce(x, group=group)
     return x
 

@@ -176,6 +176,30 @@ int mi_w4_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* 
                      const int32_t* g_idx /* nullable */, void* w_out, int64_t N, int64_t K,
                      int64_t group_size, int layout, int dtype, void* stream);
 
+/* --------------------------------------------------- TP all-reduce over xGMI (hipIpc peers) */
+
+/* Native 1-stage / 2-stage all-reduce for the latency-bound decode messages ([tokens, hidden],
+ * <= max_bytes), one process per GPU.  Every rank owns one shared allocation
+ * [signals | staging | tmp] whose hipIpc handle all peers open.  Setup functions (alloc / ipc /
+ * create / destroy / error) are init-time and DO allocate or synchronise; mi_ar_all_reduce follows
+ * the usual rules (stream-ordered, capturable, no allocation).  Sums are fp32 in rank order, so all
+ * ranks get identical bits.  Barrier spins are bounded: a missing peer sets an error flag
+ * (mi_ar_error) instead of hanging the GPU.
+ * replaces: init_custom_ar / register_buffer / all_reduce_unreg / dispose / meta_size,
+ * sgl-kernel/include/sgl_kernel_ops.h:51-68 with csrc/allreduce/custom_all_reduce.hip and
+ * custom_all_reduce_hip.cuh:155-345,541-551 (policy); Python side custom_all_reduce.py:360-497. */
+int64_t mi_ar_shared_bytes(int64_t max_bytes);
+int mi_ar_alloc_shared(int64_t bytes, void** ptr);       /* uncached device memory, zeroed */
+int mi_ar_free_shared(void* ptr);
+int mi_ar_ipc_get(void* ptr, void* handle64);            /* 64-byte hipIpcMemHandle_t */
+int mi_ar_ipc_open(const void* handle64, void** ptr);
+int mi_ar_ipc_close(void* ptr);
+void* mi_ar_create(void** shared_ptrs /* [world], own entry = local pointer */, int64_t max_bytes,
+                   int rank, int world);
+int mi_ar_destroy(void* ctx);
+int mi_ar_error(void* ctx);                               /* 0 ok, 1 a barrier timed out */
+int mi_ar_all_reduce(void* ctx, const void* inp, void* out, int64_t bytes, int dtype, void* stream);
+
 /* ------------------------------------------ layer glue (SURVEY 8f "next" rows 1-2) */
 
 /* (fused add +) RMSNorm, one row per token: x32 = x (+ residual); residual <- x32 (in place,
