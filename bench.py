@@ -43,15 +43,20 @@ def parse():
                     help="FP8 activation scale: static = serialized FP8 checkpoint with calibrated per-tensor "
                          "input scales (the reference's own FP8 test model format), dynamic = bf16 checkpoint "
                          "quantised at load, per-tensor absmax every call")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "single-GPU rehearsals of the TP path with MI_BENCH_SAME_GPU=1)")
+    ap.add_argument("--no-custom-ar", action="store_true", help="TP>1: use RCCL only (skip the native xGMI all-reduce)")
     ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
     ap.add_argument("--kernel-reps", type=int, default=3, help="passes over all layers for the roofline timing")
     return ap.parse_args()
 
 
-def dist_setup(n):
+def dist_setup(n, backend="nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MI_BENCH_SAME_GPU") == "1":   # rehearsal: every rank on GPU 0 (needs --dist-backend gloo)
+        local = 0
     if world != n:
         if world == 1 and n > 1:
             raise SystemExit(f"--gpus {n} needs torch.distributed.run with --nproc-per-node {n}")
@@ -60,9 +65,39 @@ def dist_setup(n):
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
         group = torch.distributed.group.WORLD
     return world, rank, local, group
+
+
+def make_custom_ar(world, rank, dev, msg_bytes):
+    """Native xGMI all-reduce for TP>1, self-checked against RCCL once; any problem -> RCCL only."""
+    if world == 1 or os.environ.get("MI_DISABLE_CUSTOM_AR") == "1":
+        return None
+    from iaas_sglang_amd.custom_all_reduce import CustomAllreduce
+    cpu_group = torch.distributed.new_group(backend="gloo")
+    ca = CustomAllreduce(cpu_group, dev, max_size=max(8 * 1024 * 1024, msg_bytes))   # ranks agree on .disabled
+    if ca.disabled:
+        if rank == 0:
+            print(f"[bench] native all-reduce unavailable ({ca.init_error}); using RCCL", file=sys.stderr)
+        return None
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    x = torch.randint(-4, 5, (msg_bytes // 2,), device=dev, generator=g).to(torch.bfloat16)
+    ref = x.clone()
+    torch.distributed.all_reduce(ref)
+    y = ca.all_reduce(x)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(y, ref)) and not ca.timed_out()
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if rank == 0:
+            print("[bench] native all-reduce self-check failed; using RCCL", file=sys.stderr)
+        return None
+    return ca
 
 
 def barrier_sync(world):
@@ -183,7 +218,7 @@ def cpu_baseline(shape, B, S, sample_requests=32, timed_layers=2):
 
 def main():
     a = parse()
-    world, rank, local, group = dist_setup(a.gpus)
+    world, rank, local, group = dist_setup(a.gpus, a.dist_backend)
     dev = torch.device("cuda", local)
     from iaas_sglang_amd import harness as H
     from iaas_sglang_amd.attention_backend import MiAttnBackend
@@ -202,9 +237,11 @@ def main():
     backend = MiAttnBackend(runner)
     if a.splits:
         backend._choose_splits = lambda bs, tot: a.splits
+    custom_ar = make_custom_ar(world, rank, dev, B * shape.hidden * 2) if not a.no_custom_ar else None
     static = a.act_scheme == "static"
     cfg = Fp8Config(is_checkpoint_fp8_serialized=static, activation_scheme=a.act_scheme)
-    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=tp, rank=rank, group=group)
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=tp, rank=rank, group=group,
+                         custom_ar=custom_ar)
     fb = H.make_decode_batch(runner, backend, B, S, dev, scattered=not a.contiguous, seed=0)
     ids = torch.randint(0, shape.vocab, (B,), device=dev)
     out_ids = torch.empty_like(ids)
@@ -221,7 +258,7 @@ def main():
     step()                      # eager once: allocator warm-up, lazy inits
     barrier_sync(world)
     graph = None
-    if not a.no_graph:
+    if not a.no_graph and (world == 1 or a.dist_backend == "nccl"):   # gloo collectives cannot be captured
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -277,6 +314,7 @@ def main():
                                f"bf16 paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
+                   "all_reduce": None if tp == 1 else ("native-xgmi" if custom_ar is not None else "rccl"),
                    "kv_splits": backend.forward_metadata.num_kv_splits},
         "step_hbm_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"kernel": "decode_attn_kernel (+ split merge)", "bound": "hbm", "achieved": round(achieved, 1),

@@ -31,30 +31,62 @@ class CustomAllreduce:
         self._ctx = None
         self._own = C.c_void_p()
         self._peers: List[Optional[int]] = []
+        self.init_error = ""
         if self.world_size == 1 or self.world_size not in self._SUPPORTED_WORLD_SIZES:
             return
         torch.cuda.set_device(self.device)
-        nbytes = lib.mi_ar_shared_bytes(max_size)
-        check(lib.mi_ar_alloc_shared(nbytes, C.byref(self._own)), "mi_ar_alloc_shared")
+        # Every rank takes part in every collective below even if a local step fails, and the ranks
+        # agree on the outcome at the end: one failing rank disables the path everywhere (-> RCCL)
+        # instead of leaving its peers stuck in a collective.
+        ok, why = True, ""
         handle = (C.c_char * 64)()
-        check(lib.mi_ar_ipc_get(self._own, handle), "mi_ar_ipc_get")
+        try:
+            nbytes = lib.mi_ar_shared_bytes(max_size)
+            check(lib.mi_ar_alloc_shared(nbytes, C.byref(self._own)), "mi_ar_alloc_shared")
+            check(lib.mi_ar_ipc_get(self._own, handle), "mi_ar_ipc_get")
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, str(e)
         handles: List[Optional[bytes]] = [None] * self.world_size
-        dist.all_gather_object(handles, bytes(handle.raw), group=cpu_group)
+        dist.all_gather_object(handles, bytes(handle.raw) if ok else None, group=cpu_group)
         ptrs = (C.c_void_p * self.world_size)()
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                ptrs[r] = self._own.value
-                self._peers.append(None)
-            else:
-                p = C.c_void_p()
-                check(lib.mi_ar_ipc_open(C.create_string_buffer(h, 64), C.byref(p)), "mi_ar_ipc_open")
-                ptrs[r] = p.value
-                self._peers.append(p.value)
-        self._ctx = lib.mi_ar_create(ptrs, max_size, self.rank, self.world_size)
-        if not self._ctx:
-            raise MiHotpathError(f"mi_ar_create failed: {lib.mi_last_error().decode()}")
-        dist.barrier(group=cpu_group)               # every rank has mapped every buffer
+        if ok and all(h is not None for h in handles):
+            try:
+                for r, h in enumerate(handles):
+                    if r == self.rank:
+                        ptrs[r] = self._own.value
+                        self._peers.append(None)
+                    else:
+                        p = C.c_void_p()
+                        check(lib.mi_ar_ipc_open(C.create_string_buffer(h, 64), C.byref(p)), "mi_ar_ipc_open")
+                        ptrs[r] = p.value
+                        self._peers.append(p.value)
+                self._ctx = lib.mi_ar_create(ptrs, max_size, self.rank, self.world_size)
+                if not self._ctx:
+                    raise MiHotpathError(f"mi_ar_create failed: {lib.mi_last_error().decode()}")
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, str(e)
+        else:
+            ok = False
+        status: List[Optional[bool]] = [None] * self.world_size
+        dist.all_gather_object(status, ok, group=cpu_group)   # also the "everyone has mapped everything" barrier
+        if not all(status):
+            self.init_error = why or "a peer rank failed to set up the shared buffers"
+            self._release()
+            return
         self.disabled = False
+
+    def _release(self):
+        if self._ctx:
+            lib.mi_ar_destroy(self._ctx)
+            self._ctx = None
+        for p in self._peers:
+            if p is not None:
+                lib.mi_ar_ipc_close(p)
+        self._peers = []
+        if self._own.value:
+            lib.mi_ar_free_shared(self._own)
+            self._own = C.c_void_p()
+        self.disabled = True
 
     def should_custom_ar(self, inp: torch.Tensor) -> bool:
         """custom_all_reduce.py:414-435: 16-byte multiple, contiguous, within the registered size."""
@@ -79,15 +111,8 @@ class CustomAllreduce:
     def close(self):
         if self._ctx:
             torch.cuda.synchronize()
-            dist.barrier(group=self.group)
-            lib.mi_ar_destroy(self._ctx)
-            self._ctx = None
-            for p in self._peers:
-                if p is not None:
-                    lib.mi_ar_ipc_close(p)
-            dist.barrier(group=self.group)
-            lib.mi_ar_free_shared(self._own)
-            self.disabled = True
+            dist.barrier(group=self.group)      # nobody is still reading my buffers
+            self._release()
 
     def __del__(self):
         try:

@@ -130,9 +130,9 @@ class LlamaStack:
     then final norm + lm_head.  `make_method()` returns a fresh LinearMethodBase per linear."""
 
     def __init__(self, shape: ModelShape, make_method, dtype, device, tp=1, rank=0, group=None,
-                 weight_range=1e-3, seed=1234, weights_cpu_seeded=False):
+                 weight_range=1e-3, seed=1234, weights_cpu_seeded=False, custom_ar=None):
         self.shape, self.dtype, self.device = shape, dtype, device
-        self.tp, self.rank, self.group = tp, rank, group
+        self.tp, self.rank, self.group, self.custom_ar = tp, rank, group, custom_ar
         s = shape
         self.Hq, self.Hkv = s.num_heads // tp, max(1, s.num_kv_heads // tp)
         D = s.head_dim
@@ -197,7 +197,7 @@ class LlamaStack:
             sc.data.copy_((torch.rand(sc.shape, device=dev, generator=g) * 1e-2 / 8).to(sc.dtype))
 
     def _all_reduce(self, x):
-        return tensor_model_parallel_all_reduce(x, self.tp, self.group)   # RowParallelLinear (linear.py:1376-1378)
+        return tensor_model_parallel_all_reduce(x, self.tp, self.group, self.custom_ar)   # linear.py:1376-1378
 
     def calibrate_static_input_scales(self, hidden, positions, fb, backend):
         """Give every static-activation linear a realistic `input_scale` (amax/448 of one forward pass),

@@ -35,7 +35,12 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, tp: int, group: Optional[d
     """Gather the last dim (vocab shards) from every rank."""
     if tp == 1:
         return x
-    parts = [torch.empty_like(x) for _ in range(tp)]
+    x = x.contiguous()
+    if dist.get_backend(group) == "nccl":                       # RCCL: one collective, graph-capturable
+        gathered = torch.empty((tp,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(gathered, x, group=group)
+        return gathered.movedim(0, -2).reshape(*x.shape[:-1], tp * x.shape[-1])
+    parts = [torch.empty_like(x) for _ in range(tp)]            # gloo (CPU tests, single-GPU rehearsals)
     dist.all_gather(parts, x, group=group)
     return torch.cat(parts, dim=-1)
 
