@@ -47,6 +47,7 @@ def parse():
                     "single-GPU rehearsals of the TP path with MI_BENCH_SAME_GPU=1)")
     ap.add_argument("--no-custom-ar", action="store_true", help="TP>1: use RCCL only (skip the native xGMI all-reduce)")
     ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
+    ap.add_argument("--prefill-batch", type=int, default=8, help="sequences of --seq tokens in the prefill leg (0 = skip)")
     ap.add_argument("--kernel-reps", type=int, default=3, help="passes over all layers for the roofline timing")
     return ap.parse_args()
 
@@ -137,6 +138,34 @@ def time_attention_kernel(stack, runner, backend, fb, reps):
     e1.record(stream)
     e1.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / (reps * s.layers)
+
+
+def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, reps=2):
+    """Prefill TFLOP/s (the other half of BASELINE.json's metric) on a bounded sample: one EXTEND batch
+    of `nseq` sequences x S new tokens (no cached prefix), whole layer stack, eager launches."""
+    fb = H.make_extend_batch(runner, backend, [0] * nseq, [S] * nseq, dev, seed=3)
+    T = nseq * S
+    hidden = torch.randn(T, shape.hidden, device=dev, dtype=torch.float32).to(stack.dtype)
+
+    def run():
+        backend.init_forward_metadata(fb)
+        return stack.forward(hidden, fb.positions, fb, backend, last_token_logits=fb.extend_seq_lens)
+
+    run()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    barrier_sync(world)
+    sec = (time.perf_counter() - t0) / reps
+    lin = 2.0 * T * shape.layers * ((shape.num_heads + 2 * shape.num_kv_heads) * shape.head_dim * shape.hidden
+                                    + shape.num_heads * shape.head_dim * shape.hidden + 3 * shape.intermediate * shape.hidden)
+    attn = 4.0 * shape.num_heads * shape.head_dim * nseq * (S * (S + 1) / 2) * shape.layers     # causal QK^T + PV
+    head = 2.0 * nseq * shape.vocab * shape.hidden
+    flops = lin + attn + head
+    return {"tflops": round(flops / sec / 1e12, 2), "ms": round(sec * 1e3, 2), "tokens": T,
+            "sample": f"{nseq} sequences x {S} tokens, no prefix, {shape.layers} layers, eager; "
+                      f"flops = linears {lin:.3e} + causal attention {attn:.3e} + lm_head {head:.3e}"}
 
 
 def cpu_baseline(shape, B, S, sample_requests=32, timed_layers=2):
@@ -304,6 +333,13 @@ def main():
             traffic = None
     step_bytes = (shape.layers * (abytes + (stack.q_size + 2 * stack.kv_size) * shape.hidden + stack.q_size * shape.hidden
                                   + 3 * stack.inter * shape.hidden) + stack.vocab_shard * shape.hidden * 2)
+    kv_splits = backend.forward_metadata.num_kv_splits
+    prefill = None
+    if a.prefill_batch > 0:
+        try:
+            prefill = prefill_leg(H, stack, runner, backend, shape, a.prefill_batch, S, dev, world)
+        except Exception as e:   # the decode number must not be lost to a prefill-side problem
+            prefill = {"error": f"{type(e).__name__}: {e}"}
     result = {
         "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)",
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -315,7 +351,8 @@ def main():
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
                    "all_reduce": None if tp == 1 else ("native-xgmi" if custom_ar is not None else "rccl"),
-                   "kv_splits": backend.forward_metadata.num_kv_splits},
+                   "kv_splits": kv_splits},
+        "prefill": prefill,
         "step_hbm_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"kernel": "decode_attn_kernel (+ split merge)", "bound": "hbm", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

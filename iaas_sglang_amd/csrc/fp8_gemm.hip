@@ -477,6 +477,136 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
   return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Prefill-shaped GEMM (M > 128): 256 x 256 output tile per 8-wave workgroup, K in steps of 128 B.
+//   * both operands are staged global -> LDS by LDS-DMA (64 KiB per k-step, two buffers = 128 KiB);
+//     a 1-KiB DMA piece = 8 rows x 128 B, the LDS image is lane-linear; two consecutive tile rows
+//     share one 256-B LDS line and the 16-byte position inside the line pair is XOR-swizzled with
+//     (line & 15) on the SOURCE side, which makes every ds_read_b128 fragment read conflict-free;
+//   * wave (wm, wn) of the 2 x 4 wave grid owns 128 (m) x 64 (n): 8 x 4 MFMA tiles, weights as the
+//     A operand, activations as B (each lane ends with 4 consecutive n of one output row);
+//   * v_mfma_scale_f32_16x16x128_f8f6f4, unit scales: one MFMA per (m-tile, n-tile, k-step);
+//   * one DMA-wait + barrier per k-step (stage k+1 is issued before computing k);
+//   * blocks are renumbered so that the 8 XCDs each walk a contiguous range of tiles with m fastest:
+//     the tiles resident on one XCD at a time share their weight rows in that XCD's L2.
+// Bound: MFMA (2*M*N*K flops); tile traffic 64 KiB per 16.8 MFLOP keeps L2 at ~32 B/clk/CU.
+template <typename OutT>
+__global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks) {
+  constexpr int BM = 256, BN = 256, BK = 128;
+  constexpr int TILE = BM * BK;            // 32 KiB per operand per stage
+  constexpr int STAGE = 2 * TILE;          // x tile then w tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // XCD-aware renumbering (bijective for any block count)
+  const int nwg = mblocks * nblocks;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int nb = tid / mblocks, mb = tid % mblocks;
+  const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * BN;
+  const int64_t KT = p.K / BK;
+
+  // DMA geometry: piece i (0..31 per operand) covers tile rows 8i..8i+7; lane L -> LDS byte i*1024 + L*16.
+  // LDS line pair l = row>>1, position P = L & 15 within it holds logical (rowbit, slot) = P ^ (l & 15).
+  const int dline = lane >> 4;             // 0..3: which 256-B line of the piece
+  const int dpos = lane & 15;
+#define TL_STAGE(kt_, buf_)                                                                          \
+  {                                                                                                  \
+    const int64_t kb_ = (int64_t)(kt_) * BK;                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      const int piece_ = wave * 4 + i;               /* 0..31 */                                     \
+      const int line_ = piece_ * 4 + dline;          /* LDS line pair index within the tile */       \
+      const int logical_ = dpos ^ (line_ & 15);                                                      \
+      const int row_ = line_ * 2 + (logical_ >> 3);                                                  \
+      const int slot_ = logical_ & 7;                                                                \
+      const uint8_t* xs_ = p.a + min(m0 + row_, p.M - 1) * p.lda + kb_ + slot_ * 16;                 \
+      const uint8_t* ws_ = p.b + min(n0 + row_, p.N - 1) * p.ldb + kb_ + slot_ * 16;                 \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs_,           \
+          (__attribute__((address_space(3))) void*)(smem + (buf_) * STAGE + piece_ * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ws_,           \
+          (__attribute__((address_space(3))) void*)(smem + (buf_) * STAGE + TILE + piece_ * 1024), 16, 0, 0); \
+    }                                                                                                \
+  }
+  // fragment address of (tile row, 16-byte slot): line pair = row>>1, physical pos = ((row&1)*8+slot) ^ (line&15)
+#define TL_FRAG(base_, row_, slot_) \
+  (*(const uint4*)((base_) + ((row_) >> 1) * 256 + (((((row_) & 1) << 3) | (slot_)) ^ (((row_) >> 1) & 15)) * 16))
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  TL_STAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int64_t kt = 0; kt < KT; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < KT) TL_STAGE(kt + 1, buf ^ 1);
+    const char* xb = smem + buf * STAGE;
+    const char* wb = xb + TILE;
+    i32x8 wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wn * 64 + j * 16 + r16;
+      const uint4 a0 = TL_FRAG(wb, row, q), a1 = TL_FRAG(wb, row, 4 + q);
+      wf[j] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = wm * 128 + i * 16 + r16;
+      const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
+      const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef TL_STAGE
+#undef TL_FRAG
+
+  // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
+    float sbv[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = min(nbase + r, p.N - 1);
+      sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+      bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 16 + r16;
+      if (m >= p.M) continue;
+      const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+      OutT* o = (OutT*)p.out + m * p.ldo + nbase;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sav * sbv[r] + bv[r];
+      if (nbase + 3 < p.N && (p.ldo & 3) == 0) {
+        *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nbase + r < p.N) o[r] = (OutT)v[r];
+      }
+    }
+  }
+}
+
+template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_t st) {
+  const int mblocks = (int)cdiv64(p.M, 256), nblocks = (int)cdiv64(p.N, 256);
+  fp8_gemm_tile_kernel<OutT><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks);
+}
+
 template <typename OutT>
 static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
   if (p.M <= 128 && p.K % 128 == 0 && p.rotate != 3) {  // decode shapes: x-stationary, weights streamed once
@@ -499,6 +629,10 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     else if (p.M <= 32) launch_skinny<OutT, 2>(p, st);
     else if (p.M <= 64) launch_skinny<OutT, 4>(p, st);
     else launch_skinny<OutT, 8>(p, st);
+    return;
+  }
+  if (p.K % 128 == 0 && p.rotate != 4) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
+    launch_tile<OutT>(p, st);
     return;
   }
   const unsigned gx = (unsigned)cdiv64(p.N, 64);

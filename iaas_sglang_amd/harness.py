@@ -208,8 +208,10 @@ class LlamaStack:
         finally:
             Linear.calibrating = False
 
-    def forward(self, hidden, positions, fb, backend):
-        """hidden [T, H] -> logits [T, vocab]; follows llama.py:245-268 with the fused add+norm form."""
+    def forward(self, hidden, positions, fb, backend, last_token_logits=None):
+        """hidden [T, H] -> logits [T, vocab]; follows llama.py:245-268 with the fused add+norm form.
+        last_token_logits = extend_seq_lens: logits only for each request's last token, as
+        LogitsProcessor does for extend batches (logits_processor.py:308-330)."""
         s = self.shape
         residual = None
         for L in self.layers:
@@ -228,6 +230,8 @@ class LlamaStack:
             gu = L.gate_up(x)
             hidden = self._all_reduce(L.down(ops.silu_and_mul(gu)))
         x = ops.rmsnorm(hidden, self.final_norm, s.rms_eps, residual=residual)
+        if last_token_logits is not None:
+            x = x[torch.cumsum(last_token_logits.to(torch.int64), 0) - 1]
         logits = torch.matmul(x, self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)   # logits_processor.py:464-477
 
