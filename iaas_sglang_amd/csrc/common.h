@@ -73,3 +73,21 @@ template <int N> __device__ __forceinline__ float row_bcast(float v) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// LDS-DMA (global -> LDS, 16 B per lane, LDS destination = wave-uniform byte address + lane*16) issued
+// from inline asm so that hipcc does NOT know LDS is being written asynchronously: with the builtin it
+// puts an `s_waitcnt vmcnt(0)` in front of every later ds_read that might alias, which drains the whole
+// load pipeline (weights, next stage) many times per k-step.  The caller orders DMA -> ds_read itself:
+// `s_waitcnt vmcnt(0)` (or a counted wait) followed by a workgroup barrier.  Hidden entries in the vmcnt
+// queue can only make the compiler's own counted waits more conservative, never too weak.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* shared_ptr) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)shared_ptr;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_byte_addr_uniform) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr_uniform);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}

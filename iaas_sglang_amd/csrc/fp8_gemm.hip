@@ -244,82 +244,84 @@ static void launch_skinny(const GemmParams& p, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Decode-shaped GEMM ("x-stationary"): activations live in LDS, only weights stream through VGPRs.
+// Decode-shaped GEMM (M <= 128): every operand is staged global -> LDS by LDS-DMA, MFMA reads LDS.
 //
-// Why: with every operand fetched as MFMA fragments (kernel above) each wave issues 16 activation
-// loads per 2 weight loads into ONE in-order vmcnt queue, so only ~2 KiB of weights per wave are
-// ever in flight and the CU's vector-memory path is saturated by L2-hot activation fragments
-// (measured 0.6-0.9 TB/s of weights, independent of L1/L2 residency of x).  Here
-//   * workgroup (nb, sp) = NWV waves = NWV 16-row weight tiles (one per wave) x a range of 512-byte
-//     k-phases; split-K factor S is chosen so that roughly 320 workgroups exist (small N), S = 1 when
-//     N alone provides them (then no slab traffic);
-//   * per phase the x block [M x 512 B] is copied into one of TWO LDS buffers by LDS-DMA
-//     (global_load_lds_dwordx4, 1 KiB per wave instruction = two whole 512-B row segments) while the
-//     previous phase computes; rows are unpadded (the DMA needs a lane-linear image) and the 16-byte
-//     slot index is XOR-swizzled with (row & 15) on the SOURCE address, so the ds_read_b128 fragment
-//     reads of 16 rows hit 16 distinct 4-bank groups;
-//   * each wave keeps two phases of weight fragments in registers (4 chunks x 2 KiB x 2): the vmcnt
-//     queue holds only weights + the DMA;
-//   * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the unscaled fp8 rate);
-//   * one barrier per phase; S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to
-//     slab[sp][M][N], summed by fp8_gemm_reduce_kernel.
-template <typename OutT, int MT, int NWV>
+// History of this kernel (measured on MI355X, M=128, tools/gemm_bench.py):
+//   fragments straight from HBM/L2 (kernel above): 0.6-0.9 TB/s of weights -- 16 activation loads per
+//     2 weight loads share one in-order vmcnt queue, only ~2 KiB of weights per wave in flight;
+//   activations in LDS, weights in registers: 1.0-2.3 TB/s -- hipcc cannot count register loads that
+//     are pending across the loop back-edge and drains vmcnt(0) in front of the first MFMA;
+//   this form: NO compiler-tracked vector loads in the loop at all.
+// Structure: workgroup (nb, sp) = NWV waves = NWV 16-row weight tiles x a range of 256-byte k-phases
+// (split-K factor S chosen so that ~320 workgroups exist; S = 1 when N alone provides them).  Per
+// phase the x block [M x 256 B] and each wave's weight block [16 x 256 B] are copied into one of TWO
+// LDS stages by inline-asm LDS-DMA (1 KiB per wave instruction = four 256-B row segments) while the
+// previous phase computes; rows are unpadded (the DMA image is lane-linear) and the 16-byte slot is
+// XOR-swizzled with (row & 15) on the SOURCE side, so ds_read_b128 fragment reads are conflict-free.
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales; one `vmcnt(0)` + barrier per phase.
+// S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to slab[sp][M][N], summed by
+// fp8_gemm_reduce_kernel.
+template <typename OutT, int MT, int NWV, int NST>   // NST = LDS ring depth (2 or 3 stages)
 __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
                                                                int S, int phases_per_wg) {
-  constexpr int PW = 512;               // phase width (bytes of K)
+  constexpr int PW = 256;                       // phase width (bytes of K) = 2 MFMA k-chunks
   constexpr int ROWS = MT * 16;
-  constexpr int BUF = ROWS * PW;        // one LDS buffer
+  constexpr int XBYTES = ROWS * PW;             // x block of one stage
+  constexpr int STAGE = XBYTES + NWV * 16 * PW; // + one 16-row weight block per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int64_t n0 = ((int64_t)blockIdx.x * NWV + wave) * 16;
   const int sp = blockIdx.y;
-  const int64_t KC = p.K / 128;         // K % 128 == 0 on this path
-  const int64_t NPH = (KC + 3) / 4;
+  const int64_t KC = p.K / 128;                 // K % 128 == 0 on this path
+  const int64_t NPH = (KC + 1) / 2;
   const int64_t ph0 = (int64_t)sp * phases_per_wg;
   const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
   const bool tile_ok = n0 < p.N;
+  const uint32_t lds_base = lds_addr_of(smem);
 
-  const uint8_t* wp = p.b + min(n0 + r16, p.N - 1) * p.ldb + 16 * q;
   f32x4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // DMA geometry: lane L of a wave instruction covers row (2*i + (L>>5)), LDS slot (L&31);
-  // the global source slot is swizzled: slot ^ (row & 15)
-  const int drow = lane >> 5, dslot = lane & 31;
+  // DMA geometry: one instruction = 4 rows x 256 B; lane L -> row (L >> 4), LDS slot (L & 15);
+  // the global source slot is (L & 15) ^ (row & 15)
+  const int drow = lane >> 4, dslot = lane & 15;
+  const uint8_t* wrow[4];                       // this wave's weight rows, 4 per DMA instruction
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wrow[i] = p.b + min(n0 + i * 4 + drow, p.N - 1) * p.ldb;
 
-#define XS_STAGE(ph_, buf_)                                                                        \
-  {                                                                                                \
-    const int64_t kb_ = (int64_t)(ph_) * PW;                                                       \
-    const int nslot_ = (int)min((int64_t)32, (p.K - kb_) / 16);                                    \
-    for (int rr = wave * 2; rr < ROWS; rr += NWV * 2) {                                            \
-      const int row_ = rr + drow;                                                                  \
-      int sslot_ = dslot ^ (row_ & 15);                                                            \
-      sslot_ = sslot_ < nslot_ ? sslot_ : 0;                                                       \
-      const uint8_t* src_ = p.a + min((int64_t)row_, p.M - 1) * p.lda + kb_ + sslot_ * 16;         \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,        \
-                                       (__attribute__((address_space(3))) void*)(smem + (buf_) * BUF + rr * PW), 16, 0, 0); \
-    }                                                                                              \
+#define XS_STAGE(ph_, st_)                                                                          \
+  {                                                                                                 \
+    const int64_t kb_ = (int64_t)(ph_) * PW;                                                        \
+    const int nslot_ = (int)min((int64_t)16, (p.K - kb_) / 16);                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {             /* weights: rows 4i .. 4i+3 */      \
+      const int row_ = i * 4 + drow;                                                                \
+      int ss_ = dslot ^ (row_ & 15);                                                                \
+      ss_ = ss_ < nslot_ ? ss_ : 0;                                                                 \
+      glds16(wrow[i] + kb_ + ss_ * 16, lds_base + (st_) * STAGE + XBYTES + (wave * 16 + i * 4) * PW); \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < (ROWS / 4 + NWV - 1) / NWV; ++i) {   /* x rows */         \
+      const int rr_ = (i * NWV + wave) * 4;                                                         \
+      if (rr_ < ROWS) {                                                                             \
+        const int row_ = rr_ + drow;                                                                \
+        int ss_ = dslot ^ (row_ & 15);                                                              \
+        ss_ = ss_ < nslot_ ? ss_ : 0;                                                               \
+        glds16(p.a + min((int64_t)row_, p.M - 1) * p.lda + kb_ + ss_ * 16, lds_base + (st_) * STAGE + rr_ * PW); \
+      }                                                                                             \
+    }                                                                                               \
   }
-#define XS_WLOAD(W0, W1, ph_)                                                   \
-  {                                                                             \
-    const int64_t c0_ = (int64_t)(ph_) * 4;                                     \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                             \
-      const int64_t kb_ = min(c0_ + c, KC - 1) * 128;                           \
-      W0[c] = *(const uint4*)(wp + kb_);                                        \
-      W1[c] = *(const uint4*)(wp + kb_ + 64);                                   \
-    }                                                                           \
-  }
-#define XS_MMA(W0, W1, ph_, buf_)                                                                          \
+#define XS_MMA(ph_, st_)                                                                                   \
   if (tile_ok) {                                                                                           \
-    const int nch_ = (int)min((int64_t)4, KC - (int64_t)(ph_) * 4);                                        \
-    const char* xb_ = smem + (buf_) * BUF + r16 * PW;                                                      \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                        \
+    const int nch_ = (int)min((int64_t)2, KC - (int64_t)(ph_) * 2);                                        \
+    const char* xb_ = smem + (st_) * STAGE + r16 * PW;                                                     \
+    const char* wb_ = smem + (st_) * STAGE + XBYTES + (wave * 16 + r16) * PW;                              \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                        \
       if (c < nch_) {                                                                                      \
-        const i32x8 wf_ = {(int)W0[c].x, (int)W0[c].y, (int)W0[c].z, (int)W0[c].w,                         \
-                           (int)W1[c].x, (int)W1[c].y, (int)W1[c].z, (int)W1[c].w};                        \
         const int o0_ = ((c * 8 + q) ^ r16) * 16, o1_ = ((c * 8 + 4 + q) ^ r16) * 16;                      \
+        const uint4 w0_ = *(const uint4*)(wb_ + o0_), w1_ = *(const uint4*)(wb_ + o1_);                    \
+        const i32x8 wf_ = {(int)w0_.x, (int)w0_.y, (int)w0_.z, (int)w0_.w,                                 \
+                           (int)w1_.x, (int)w1_.y, (int)w1_.z, (int)w1_.w};                                \
         _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                   \
           const uint4 x0_ = *(const uint4*)(xb_ + t * 16 * PW + o0_);                                      \
           const uint4 x1_ = *(const uint4*)(xb_ + t * 16 * PW + o1_);                                      \
@@ -330,38 +332,50 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
       }                                                                                                    \
     }                                                                                                      \
   }
-
-  uint4 wa0[4], wa1[4], wb0[4], wb1[4];
+  // NST stages in an LDS ring: NST-1 phases are in flight while one computes.  Each wave issues DPP DMA
+  // instructions per phase, so "phase ph+1 has landed, ph+2 may still fly" is a COUNTED wait vmcnt(DPP)
+  // (loads retire in order); the barrier then publishes every wave's pieces of phase ph+1.
+  constexpr int DPP = 4 + (ROWS / 4 + NWV - 1) / NWV;   // DMA instructions per wave per phase
+#define XS_BARRIER_AFTER(N_)                                      \
+  {                                                               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");     \
+    __syncthreads();                                              \
+  }
   if (ph0 < ph1) {
-    XS_WLOAD(wa0, wa1, ph0);
-    XS_STAGE(ph0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int64_t ph = ph0; ph < ph1; ph += 2) {
-      // ---- even phase: compute (A regs, buffer 0) while phase ph+1 lands (B regs, buffer 1)
-      const bool has1 = ph + 1 < ph1;
-      if (has1) {
-        XS_WLOAD(wb0, wb1, ph + 1);
-        XS_STAGE(ph + 1, 1);
+    if constexpr (NST == 2) {
+      XS_STAGE(ph0, 0);
+      XS_BARRIER_AFTER(0);
+      for (int64_t ph = ph0; ph < ph1; ++ph) {
+        const int st = (int)((ph - ph0) & 1);
+        if (ph + 1 < ph1) XS_STAGE(ph + 1, st ^ 1);
+        XS_MMA(ph, st);
+        XS_BARRIER_AFTER(0);
       }
-      XS_MMA(wa0, wa1, ph, 0);
-      if (!has1) break;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // ---- odd phase
-      const bool has2 = ph + 2 < ph1;
-      if (has2) {
-        XS_WLOAD(wa0, wa1, ph + 2);
-        XS_STAGE(ph + 2, 0);
+    } else {
+      XS_STAGE(ph0, 0);
+      if (ph0 + 1 < ph1) {
+        XS_STAGE(ph0 + 1, 1);
+        XS_BARRIER_AFTER(DPP);
+      } else {
+        XS_BARRIER_AFTER(0);
       }
-      XS_MMA(wb0, wb1, ph + 1, 1);
-      if (!has2) break;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      int st = 0;
+      for (int64_t ph = ph0; ph < ph1; ++ph) {
+        const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
+        if (ph + 2 < ph1) {
+          XS_STAGE(ph + 2, st2);
+          XS_MMA(ph, st);
+          XS_BARRIER_AFTER(DPP);                // phase ph+1 landed, ph+2 in flight
+        } else {
+          XS_MMA(ph, st);
+          XS_BARRIER_AFTER(0);
+        }
+        st = st == 2 ? 0 : st + 1;
+      }
     }
   }
+#undef XS_BARRIER_AFTER
 #undef XS_STAGE
-#undef XS_WLOAD
 #undef XS_MMA
   if (!tile_ok) return;
 
@@ -444,12 +458,20 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
   }
 }
 
+static int xs_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 // waves per workgroup: 8 when N alone yields >= ~200 workgroups of 128 rows, else 4
-static int xs_waves(int64_t N) { return cdiv64(N, 128) >= 200 ? 8 : 4; }
+static int xs_waves(int64_t N) {
+  static const int big = xs_env("MI_GEMM_XS_NW", 8);
+  return (cdiv64(N, 128) >= 200 && big == 8) ? 8 : 4;
+}
 
 static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
-  const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 4);
-  int64_t want = nblk >= 200 ? 1 : cdiv64(320, nblk);
+  const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 2);
+  static const int target = xs_env("MI_GEMM_XS_TARGET", 320);
+  int64_t want = nblk >= 200 ? 1 : cdiv64(target, nblk);
   if (want < 1) want = 1;
   if (want > nph) want = nph;
   const int64_t per = cdiv64(nph, want);
@@ -459,11 +481,13 @@ static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
 
 template <typename OutT, int MT>
 static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st) {
-  const size_t lds = (size_t)2 * MT * 16 * 512;
   const int nw = xs_waves(p.N);
+  static const int nst4 = xs_env("MI_GEMM_XS_STAGES", 3);
+  const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
   dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
-  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8><<<grid, 512, lds, st>>>(p, slab, S, ppw);
-  else fp8_gemm_xs_kernel<OutT, MT, 4><<<grid, 256, lds, st>>>(p, slab, S, ppw);
+  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw);
+  else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw);
+  else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw);
   if (S > 1) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, slab, S);
@@ -514,6 +538,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   // LDS line pair l = row>>1, position P = L & 15 within it holds logical (rowbit, slot) = P ^ (l & 15).
   const int dline = lane >> 4;             // 0..3: which 256-B line of the piece
   const int dpos = lane & 15;
+  const uint32_t lds_base = lds_addr_of(smem);
 #define TL_STAGE(kt_, buf_)                                                                          \
   {                                                                                                  \
     const int64_t kb_ = (int64_t)(kt_) * BK;                                                         \
@@ -525,10 +550,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       const int slot_ = logical_ & 7;                                                                \
       const uint8_t* xs_ = p.a + min(m0 + row_, p.M - 1) * p.lda + kb_ + slot_ * 16;                 \
       const uint8_t* ws_ = p.b + min(n0 + row_, p.N - 1) * p.ldb + kb_ + slot_ * 16;                 \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs_,           \
-          (__attribute__((address_space(3))) void*)(smem + (buf_) * STAGE + piece_ * 1024), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ws_,           \
-          (__attribute__((address_space(3))) void*)(smem + (buf_) * STAGE + TILE + piece_ * 1024), 16, 0, 0); \
+      glds16(xs_, lds_base + (buf_) * STAGE + piece_ * 1024);                                        \
+      glds16(ws_, lds_base + (buf_) * STAGE + TILE + piece_ * 1024);                                 \
     }                                                                                                \
   }
   // fragment address of (tile row, 16-byte slot): line pair = row>>1, physical pos = ((row&1)*8+slot) ^ (line&15)
@@ -615,7 +638,7 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
     if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {  // no room for slabs: no split-K
       S = 1;
-      spw = (int)cdiv64(p.K / 128, 4);
+      spw = (int)cdiv64(p.K / 128, 2);
     }
     float* slab = (float*)workspace;
     if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st);
