@@ -48,6 +48,8 @@ SIGNATURES = {
     "mi_ar_error": (_int, [_p]),
     "mi_ar_all_reduce": (_int, [_p, _p, _p, _i64, _int, _p]),
     "mi_rmsnorm": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
+    "mi_rmsnorm_fp8": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
+    "mi_silu_and_mul_fp8": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_rope_neox": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_silu_and_mul": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_w4_dequantize": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),

@@ -21,10 +21,23 @@ template <typename T> __device__ __forceinline__ uint4 pack8f(const float (&f)[8
 // ---------------------------------------------------------------- (fused add +) RMSNorm
 // layers/layernorm.py:128-146 (forward_native): x32 = x (+ residual); residual = x32 -> T;
 // out = (x32 * rsqrt(mean(x32^2) + eps) * w) -> T.   One 256-thread workgroup per row.
+// 8 floats (already rounded to T) -> 8 fp8 bytes with the static per-tensor scale: identical bits to
+// running mi_fp8_quant_per_tensor (mode 1) on the T-typed output.
+__device__ __forceinline__ uint2 quant8_static(const float (&f)[8], float inv) {
+  uint32_t lo = 0, hi = 0;
+  auto c = [](float v) { return fmaxf(fminf(v, 448.0f), -448.0f); };
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[0] * inv), c(f[1] * inv), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[2] * inv), c(f[3] * inv), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[4] * inv), c(f[5] * inv), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[6] * inv), c(f[7] * inv), hi, true);
+  return make_uint2(lo, hi);
+}
+
 template <typename T, int VPT>  // VPT 16-byte vectors per thread (H <= 256*8*VPT)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, T* __restrict__ residual,
                                                       const T* __restrict__ w, T* __restrict__ out, int64_t H,
-                                                      int64_t ldx, int64_t ldr, int64_t ldo, float eps) {
+                                                      int64_t ldx, int64_t ldr, int64_t ldo, float eps,
+                                                      uint8_t* __restrict__ q_out, const float* __restrict__ q_scale) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const int64_t nvec = H / 8;
@@ -60,23 +73,32 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, T
       unpack8f<T>(*(const uint4*)(w + c * 8), wf);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
-      *(uint4*)(out + row * ldo + c * 8) = pack8f<T>(o);
+      if (out) *(uint4*)(out + row * ldo + c * 8) = pack8f<T>(o);
+      if (q_out) {
+        const float qs = *q_scale;
+        const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rnd<T>(o[j]);
+        *(uint2*)(q_out + row * H + c * 8) = quant8_static(o, qinv);
+      }
     }
   }
 }
 
-extern "C" int mi_rmsnorm(const void* x, void* residual, const void* weight, void* out, int64_t M, int64_t H,
-                          int64_t ldx, int64_t ldr, int64_t ldo, float eps, int dtype, void* stream) {
+static int rmsnorm_impl(const void* x, void* residual, const void* weight, void* out, int64_t M, int64_t H,
+                        int64_t ldx, int64_t ldr, int64_t ldo, float eps, int dtype, void* stream, void* q_out,
+                        const float* q_scale) {
   MI_CHECK_ARG(M >= 0 && H > 0);
   if (M == 0) return MI_OK;
-  MI_CHECK_ARG(x && weight && out);
+  MI_CHECK_ARG(x && weight && (out || q_out));
+  MI_CHECK_ARG(!q_out || q_scale);
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (H % 8 != 0 || H > 256 * 8 * 8 || ldx % 8 || ldo % 8 || (residual && ldr % 8))
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_rmsnorm: H must be a multiple of 8 and <= 16384 (H=%lld)", (long long)H);
   hipStream_t st = (hipStream_t)stream;
   const int vpt = (int)cdiv64(H / 8, 256);
 #define LAUNCH_RMS(TT, V) \
-  rmsnorm_kernel<TT, V><<<(unsigned)M, 256, 0, st>>>((const TT*)x, (TT*)residual, (const TT*)weight, (TT*)out, H, ldx, ldr, ldo, eps)
+  rmsnorm_kernel<TT, V><<<(unsigned)M, 256, 0, st>>>((const TT*)x, (TT*)residual, (const TT*)weight, (TT*)out, H, ldx, ldr, ldo, eps, (uint8_t*)q_out, q_scale)
   if (dtype == MI_BF16) {
     if (vpt <= 1) LAUNCH_RMS(bf16_t, 1); else if (vpt <= 2) LAUNCH_RMS(bf16_t, 2); else if (vpt <= 4) LAUNCH_RMS(bf16_t, 4); else LAUNCH_RMS(bf16_t, 8);
   } else {
@@ -85,6 +107,19 @@ extern "C" int mi_rmsnorm(const void* x, void* residual, const void* weight, voi
 #undef LAUNCH_RMS
   MI_CHECK_LAUNCH();
   return MI_OK;
+}
+
+extern "C" int mi_rmsnorm(const void* x, void* residual, const void* weight, void* out, int64_t M, int64_t H,
+                          int64_t ldx, int64_t ldr, int64_t ldo, float eps, int dtype, void* stream) {
+  MI_CHECK_ARG(out != nullptr);
+  return rmsnorm_impl(x, residual, weight, out, M, H, ldx, ldr, ldo, eps, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int mi_rmsnorm_fp8(const void* x, void* residual, const void* weight, void* out, void* q_out,
+                              const float* q_scale, int64_t M, int64_t H, int64_t ldx, int64_t ldr, int64_t ldo,
+                              float eps, int dtype, void* stream) {
+  MI_CHECK_ARG(q_out != nullptr && q_scale != nullptr);
+  return rmsnorm_impl(x, residual, weight, out, M, H, ldx, ldr, ldo, eps, dtype, stream, q_out, q_scale);
 }
 
 // ------------------------------------------------------------------------- NeoX RoPE
@@ -142,7 +177,13 @@ extern "C" int mi_rope_neox(void* q, void* k, const int64_t* positions, const fl
 // layers/activation.py:56-58: F.silu(x[..., :d]) * x[..., d:]  (silu rounded to T, then the product)
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t M,
-                                                       int64_t I, int64_t ldx, int64_t ldo) {
+                                                       int64_t I, int64_t ldx, int64_t ldo,
+                                                       uint8_t* __restrict__ q_out, const float* __restrict__ q_scale) {
+  float qinv = 0.f;
+  if (q_out) {
+    const float qs = *q_scale;
+    qinv = qs > 0.f ? 1.0f / qs : 0.f;
+  }
   const int64_t vpr = I / 8;
   for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < M * vpr; gid += (int64_t)gridDim.x * 256) {
     const int64_t r = gid / vpr, c = gid % vpr;
@@ -151,22 +192,40 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ x, 
     unpack8f<T>(*(const uint4*)(x + r * ldx + I + c * 8), b);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = rnd<T>(a[j] / (1.f + expf(-a[j]))) * b[j];
-    *(uint4*)(out + r * ldo + c * 8) = pack8f<T>(o);
+    if (out) *(uint4*)(out + r * ldo + c * 8) = pack8f<T>(o);
+    if (q_out) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rnd<T>(o[j]);
+      *(uint2*)(q_out + r * I + c * 8) = quant8_static(o, qinv);
+    }
   }
 }
 
-extern "C" int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx, int64_t ldo, int dtype,
-                               void* stream) {
+static int silu_impl(const void* x, void* out, int64_t M, int64_t I, int64_t ldx, int64_t ldo, int dtype, void* stream,
+                     void* q_out, const float* q_scale) {
   MI_CHECK_ARG(M >= 0 && I > 0);
   if (M == 0) return MI_OK;
-  MI_CHECK_ARG(x && out);
+  MI_CHECK_ARG(x && (out || q_out));
+  MI_CHECK_ARG(!q_out || q_scale);
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (I % 8 || ldx % 8 || ldo % 8) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_silu_and_mul: sizes must be multiples of 8");
   const int64_t total = M * (I / 8);
   const unsigned blocks = (unsigned)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MI_BF16) silu_mul_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, M, I, ldx, ldo);
-  else silu_mul_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (f16_t*)out, M, I, ldx, ldo);
+  if (dtype == MI_BF16) silu_mul_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, M, I, ldx, ldo, (uint8_t*)q_out, q_scale);
+  else silu_mul_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (f16_t*)out, M, I, ldx, ldo, (uint8_t*)q_out, q_scale);
   MI_CHECK_LAUNCH();
   return MI_OK;
+}
+
+extern "C" int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx, int64_t ldo, int dtype,
+                               void* stream) {
+  MI_CHECK_ARG(out != nullptr);
+  return silu_impl(x, out, M, I, ldx, ldo, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int mi_silu_and_mul_fp8(const void* x, void* out, void* q_out, const float* q_scale, int64_t M, int64_t I,
+                                   int64_t ldx, int64_t ldo, int dtype, void* stream) {
+  MI_CHECK_ARG(q_out != nullptr && q_scale != nullptr);
+  return silu_impl(x, out, M, I, ldx, ldo, dtype, stream, q_out, q_scale);
 }

@@ -93,6 +93,18 @@ class Linear(torch.nn.Module):
 
     calibrating = False   # class-wide switch used by LlamaStack.calibrate_static_input_scales
 
+    def fused_quant_scale(self):
+        """Static input scale when the producer may hand this linear an fp8 activation directly."""
+        if Linear.calibrating or not Linear.fuse_producer_quant:
+            return None
+        f = getattr(self.quant_method, "static_input_scale", None)
+        return f(self) if f is not None else None
+
+    def forward_prequantized(self, qx, out_dtype):
+        return self.quant_method.apply_prequantized(self, qx, out_dtype, self.bias)
+
+    fuse_producer_quant = True   # SURVEY 8f row 2: norm/activation kernels emit fp8 for static-scale linears
+
     def forward(self, x):
         if Linear.calibrating and getattr(self, "input_scale", None) is not None:
             # one-off calibration of a static per-tensor activation scale (what an FP8 checkpoint ships):
@@ -215,20 +227,33 @@ class LlamaStack:
         s = self.shape
         residual = None
         for L in self.layers:
-            if residual is None:
+            first = residual is None
+            if first:
                 residual = hidden
-                x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps)
+            qs = L.qkv.fused_quant_scale()
+            if qs is not None:
+                qkv = L.qkv.forward_prequantized(
+                    ops.rmsnorm_fp8(hidden, L.input_norm, s.rms_eps, qs, residual=None if first else residual),
+                    self.dtype)
             else:
-                x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps, residual=residual)
-            qkv = L.qkv(x)
+                x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps, residual=None if first else residual)
+                qkv = L.qkv(x)
             q, k, v = qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size], qkv[:, self.q_size + self.kv_size:]
             ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
             a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
                                 L.attn, fb)
             hidden = self._all_reduce(L.o(a))
-            x = ops.rmsnorm(hidden, L.post_norm, s.rms_eps, residual=residual)
-            gu = L.gate_up(x)
-            hidden = self._all_reduce(L.down(ops.silu_and_mul(gu)))
+            qs = L.gate_up.fused_quant_scale()
+            if qs is not None:
+                gu = L.gate_up.forward_prequantized(
+                    ops.rmsnorm_fp8(hidden, L.post_norm, s.rms_eps, qs, residual=residual), self.dtype)
+            else:
+                gu = L.gate_up(ops.rmsnorm(hidden, L.post_norm, s.rms_eps, residual=residual))
+            qs = L.down.fused_quant_scale()
+            if qs is not None:
+                hidden = self._all_reduce(L.down.forward_prequantized(ops.silu_and_mul_fp8(gu, qs), self.dtype))
+            else:
+                hidden = self._all_reduce(L.down(ops.silu_and_mul(gu)))
         x = ops.rmsnorm(hidden, self.final_norm, s.rms_eps, residual=residual)
         if last_token_logits is not None:
             x = x[torch.cumsum(last_token_logits.to(torch.int64), 0) - 1]

@@ -292,3 +292,25 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     check(lib.mi_silu_and_mul(_ptr(x), _ptr(out), M, I2 // 2, x.stride(0), out.stride(0), _dt(x), _stream()),
           "mi_silu_and_mul")
     return out
+
+
+def rmsnorm_fp8(x: torch.Tensor, weight: torch.Tensor, eps: float, q_scale: torch.Tensor,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rmsnorm (+ in-place residual add) with the static per-tensor FP8 quantisation of the following
+    linear fused in: returns fp8 [M,H]; bit-identical to rmsnorm() followed by fp8_quant_per_tensor(scale)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous() and q_scale.dtype == torch.float32
+    M, H = x.shape
+    q = torch.empty(M, H, dtype=FP8_DTYPE, device=x.device)
+    check(lib.mi_rmsnorm_fp8(_ptr(x), _ptr(residual), _ptr(weight), None, _ptr(q), _ptr(q_scale), M, H, x.stride(0),
+                             residual.stride(0) if residual is not None else 0, 0, float(eps), _dt(x), _stream()),
+          "mi_rmsnorm_fp8")
+    return q
+
+
+def silu_and_mul_fp8(x: torch.Tensor, q_scale: torch.Tensor) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1 and q_scale.dtype == torch.float32
+    M, I2 = x.shape
+    q = torch.empty(M, I2 // 2, dtype=FP8_DTYPE, device=x.device)
+    check(lib.mi_silu_and_mul_fp8(_ptr(x), None, _ptr(q), _ptr(q_scale), M, I2 // 2, x.stride(0), 0, _dt(x),
+                                  _stream()), "mi_silu_and_mul_fp8")
+    return q

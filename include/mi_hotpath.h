@@ -210,6 +210,16 @@ int mi_rmsnorm(const void* x, void* residual /* nullable, in/out */, const void*
                int64_t M, int64_t H, int64_t ldx, int64_t ldr, int64_t ldo, float eps, int dtype,
                void* stream);
 
+/* The same two producers with a fused static per-tensor FP8 output: q_out fp8
+ * [M,H] / [M,I] contiguous = quantise(T-rounded result, *q_scale), bit-identical to running
+ * mi_fp8_quant_per_tensor(mode 1) on `out`; `out` (nullable) is still written when given.
+ * replaces: norm/activation + scaled_fp8_quant pairs in front of an FP8 linear (fp8_utils.py:654-674). */
+int mi_rmsnorm_fp8(const void* x, void* residual, const void* weight, void* out /* nullable */,
+                   void* q_out, const float* q_scale, int64_t M, int64_t H, int64_t ldx, int64_t ldr,
+                   int64_t ldo, float eps, int dtype, void* stream);
+int mi_silu_and_mul_fp8(const void* x, void* out /* nullable */, void* q_out, const float* q_scale,
+                        int64_t M, int64_t I, int64_t ldx, int64_t ldo, int dtype, void* stream);
+
 /* In-place NeoX rotary embedding on q [tokens,Hq,D] and k [tokens,Hkv,D] (rotary_dim == D);
  * cos_sin_cache fp32 [max_pos, D] = [cos(D/2) | sin(D/2)], positions int64 [tokens].
  * replaces: RotaryEmbedding.forward_native, layers/rotary_embedding.py:49-74,138-166

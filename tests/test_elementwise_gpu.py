@@ -59,3 +59,27 @@ def test_silu_and_mul(dtype):
     ulp = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
     # two roundings (silu, then the product): allow 2 ulp of the output dtype
     torch.testing.assert_close(out.cpu().float(), oe.silu_and_mul(x).float(), rtol=4 * ulp, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_fp8_producers_equal_unfused_pair(dtype):
+    """rmsnorm_fp8 / silu_and_mul_fp8 == producer followed by the static per-tensor quant kernel, bit for bit."""
+    o_ = ops()
+    g = torch.Generator().manual_seed(5)
+    M, H = 128, 4096
+    x = torch.randn(M, H, generator=g).to(dtype).to(DEV)
+    r = torch.randn(M, H, generator=g).to(dtype).to(DEV)
+    w = (torch.rand(H, generator=g) + 0.5).to(dtype).to(DEV)
+    scale = torch.tensor([0.011], device=DEV)
+    r1, r2 = r.clone(), r.clone()
+    q_fused = o_.rmsnorm_fp8(x, w, 1e-5, scale, residual=r1)
+    q_ref, _ = o_.fp8_quant_per_tensor(o_.rmsnorm(x, w, 1e-5, residual=r2), scale)
+    assert torch.equal(r1, r2)
+    assert torch.equal(q_fused.view(torch.uint8), q_ref.view(torch.uint8))
+    q_fused = o_.rmsnorm_fp8(x, w, 1e-5, scale)
+    q_ref, _ = o_.fp8_quant_per_tensor(o_.rmsnorm(x, w, 1e-5), scale)
+    assert torch.equal(q_fused.view(torch.uint8), q_ref.view(torch.uint8))
+    gu = (torch.randn(M, 2 * 14336, generator=g) * 2).to(dtype).to(DEV)
+    q_fused = o_.silu_and_mul_fp8(gu, scale)
+    q_ref, _ = o_.fp8_quant_per_tensor(o_.silu_and_mul(gu), scale)
+    assert torch.equal(q_fused.view(torch.uint8), q_ref.view(torch.uint8))
