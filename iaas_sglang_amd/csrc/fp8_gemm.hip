@@ -462,16 +462,17 @@ static int xs_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// waves per workgroup: 8 when N alone yields >= ~200 workgroups of 128 rows, else 4
+// waves per workgroup: 8 (two per SIMD: one wave's DMA issue overlaps the other's MFMAs) unless
+// MI_GEMM_XS_NW=4 or the problem is too narrow to give 128-row blocks
 static int xs_waves(int64_t N) {
   static const int big = xs_env("MI_GEMM_XS_NW", 8);
-  return (cdiv64(N, 128) >= 200 && big == 8) ? 8 : 4;
+  return (big == 8 && N >= 1024) ? 8 : 4;
 }
 
 static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
   const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 2);
-  static const int target = xs_env("MI_GEMM_XS_TARGET", 320);
-  int64_t want = nblk >= 200 ? 1 : cdiv64(target, nblk);
+  static const int target = xs_env("MI_GEMM_XS_TARGET", 256);   // one round of workgroups on 256 CUs
+  int64_t want = nblk >= 200 ? 1 : target / nblk;
   if (want < 1) want = 1;
   if (want > nph) want = nph;
   const int64_t per = cdiv64(nph, want);
