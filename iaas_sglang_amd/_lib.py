@@ -36,7 +36,8 @@ SIGNATURES = {
     "mi_fp8_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _p, _i64, _p]),
     "mi_fp8_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "mi_w4_repack": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
-    "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
+    "mi_w4a16_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "mi_ar_shared_bytes": (_i64, [_i64]),
     "mi_ar_alloc_shared": (_int, [_i64, C.POINTER(C.c_void_p)]),
     "mi_ar_free_shared": (_int, [_p]),

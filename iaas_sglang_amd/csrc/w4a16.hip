@@ -206,6 +206,179 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const W4Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Decode-shaped fused dequant GEMM (M <= 128, no act-order): same structure as fp8_gemm_xs_kernel.
+//   workgroup (nb, sp) = NWV waves = NWV 16-column weight tiles x a range of 128-element k-phases;
+//   per phase the activation block [M x 256 B] (fp16/bf16) and each wave's packed int4 block (one
+//   1-KiB native tile = 16 n x 128 k) go global -> LDS by inline-asm LDS-DMA into a 2-stage ring while
+//   the previous phase computes; the (scale, zero) words of the workgroup's whole k-range are staged
+//   once; x rows are unpadded with the 16-byte slot XOR-swizzled by (row & 15) on the source side.
+//   Per phase and wave: 1 ds_read_b128 of packed weights -> 4 dequantised MFMA fragments (exact
+//   (w - z) * s), 4 x MT MFMA 16x16x32.  Split-K partials go to fp32 slabs (w4_reduce_kernel).
+// Bound: HBM (N*K/2 bytes of weights read once) + per-CU ingest of the activation block.
+template <typename T, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, float* __restrict__ slab, int S,
+                                                            int phases_per_wg) {
+  typedef typename Elem<T>::vec8 vec8;
+  constexpr int PW = 256;                            // bytes of x per row per phase (128 elements)
+  constexpr int ROWS = MT * 16;
+  constexpr int XBYTES = ROWS * PW;
+  constexpr int STAGE = XBYTES + NWV * 1024;         // + one packed weight tile per wave
+  constexpr int MAXPH = 32;                          // zs staging capacity (phases per workgroup)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* zs_lds = (uint32_t*)(smem + 2 * STAGE);  // [NWV][MAXPH][16]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t nt = (int64_t)blockIdx.x * NWV + wave;
+  const int64_t n0 = nt * 16;
+  const int sp = blockIdx.y;
+  const int64_t KB = p.K / 128;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(KB, ph0 + phases_per_wg);
+  const bool tile_ok = n0 < p.N;
+  const uint32_t lds_base = lds_addr_of(smem);
+  const int drow = lane >> 4, dslot = lane & 15;
+  const uint4* wq = (const uint4*)p.qw + min(nt, p.N / 16 - 1) * KB * 64 + lane;
+
+  // (scale, zero) words of this wave's 16 columns for every phase of the workgroup: staged once
+  if (tile_ok) {
+    for (int i = lane; i < (int)(ph1 - ph0) * 16; i += 64) {
+      const int64_t ph = ph0 + i / 16;
+      zs_lds[(wave * MAXPH + i / 16) * 16 + (i & 15)] = p.zs[((ph * 128) / p.group) * p.N + n0 + (i & 15)];
+    }
+  }
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define W4_STAGE(ph_, st_)                                                                             \
+  {                                                                                                    \
+    glds16(wq + (int64_t)(ph_) * 64, lds_base + (st_) * STAGE + XBYTES + wave * 1024);                 \
+    _Pragma("unroll") for (int i = 0; i < (ROWS / 4 + NWV - 1) / NWV; ++i) {                           \
+      const int rr_ = (i * NWV + wave) * 4;                                                            \
+      if (rr_ < ROWS) {                                                                                \
+        const int row_ = rr_ + drow;                                                                   \
+        const int ss_ = dslot ^ (row_ & 15);                                                           \
+        glds16((const T*)p.x + min((int64_t)row_, p.M - 1) * p.ldx + (int64_t)(ph_) * 128 + ss_ * 8,   \
+               lds_base + (st_) * STAGE + rr_ * PW);                                                   \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define W4_MMA(ph_, st_)                                                                               \
+  if (tile_ok) {                                                                                       \
+    const uint4 wv_ = *(const uint4*)(smem + (st_) * STAGE + XBYTES + wave * 1024 + lane * 16);        \
+    const uint32_t ww_[4] = {wv_.x, wv_.y, wv_.z, wv_.w};                                              \
+    const uint32_t zsv_ = zs_lds[(wave * MAXPH + (int)((ph_) - ph0)) * 16 + r16];                      \
+    const char* xb_ = smem + (st_) * STAGE + r16 * PW;                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+      const vec8 wf_ = Deq<T>::run(ww_[s], zsv_);                                                      \
+      const int o_ = ((s * 4 + q) ^ r16) * 16;                                                         \
+      _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                 \
+        const vec8 xf_ = __builtin_bit_cast(vec8, *(const uint4*)(xb_ + t * 16 * PW + o_));            \
+        acc[t] = Elem<T>::mfma16(wf_, xf_, acc[t]);                                                    \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define W4_WAIT()                                       \
+  {                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+    __syncthreads();                                    \
+  }
+  if (ph0 < ph1) {
+    W4_STAGE(ph0, 0);
+    W4_WAIT();
+    for (int64_t ph = ph0; ph < ph1; ++ph) {
+      const int st = (int)((ph - ph0) & 1);
+      if (ph + 1 < ph1) W4_STAGE(ph + 1, st ^ 1);
+      W4_MMA(ph, st);
+      W4_WAIT();
+    }
+  }
+#undef W4_STAGE
+#undef W4_MMA
+#undef W4_WAIT
+  if (!tile_ok) return;
+
+  const int64_t nb = n0 + 4 * q;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int64_t m = (int64_t)t * 16 + r16;
+    if (m >= p.M) continue;
+    if (S > 1) {
+      *(f32x4*)(slab + ((int64_t)sp * p.M + m) * p.N + nb) = acc[t];
+    } else {
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = p.bias ? (float)((const T*)p.bias)[nb + r] : 0.f;
+      *(uint2*)((T*)p.out + m * p.ldo + nb) = make_uint2(pack2<T>(acc[t][0] + bv[0], acc[t][1] + bv[1]),
+                                                        pack2<T>(acc[t][2] + bv[2], acc[t][3] + bv[3]));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void w4_reduce_kernel(const W4Params p, const float* __restrict__ slab, int S) {
+  const int64_t nq = p.N / 4;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= p.M * nq) return;
+  const int64_t m = gid / nq, nb = (gid % nq) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) v += *(const f32x4*)(slab + ((int64_t)s * p.M + m) * p.N + nb);
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = p.bias ? (float)((const T*)p.bias)[nb + r] : 0.f;
+  *(uint2*)((T*)p.out + m * p.ldo + nb) = make_uint2(pack2<T>(v[0] + bv[0], v[1] + bv[1]), pack2<T>(v[2] + bv[2], v[3] + bv[3]));
+}
+
+static void w4_plan(int64_t N, int64_t K, int* S, int* ppw) {
+  const int64_t nblk = cdiv64(N, 128), nph = K / 128;
+  int64_t want = nblk >= 200 ? 1 : 256 / nblk;
+  if (want < 1) want = 1;
+  if (want > nph) want = nph;
+  int64_t per = cdiv64(nph, want);
+  if (per > 32) per = 32;                 // zs staging capacity
+  *ppw = (int)per;
+  *S = (int)cdiv64(nph, per);
+}
+
+extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M > 128 || M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  int S, ppw;
+  w4_plan(N, K, &S, &ppw);
+  return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+}
+
+template <typename T, int MT>
+static void launch_w4_xs(const W4Params& p, float* slab, int S, int ppw, hipStream_t st) {
+  constexpr int NWV = 8;
+  const size_t lds = (size_t)2 * (MT * 16 * 256 + NWV * 1024) + (size_t)NWV * 32 * 16 * 4;
+  dim3 grid((unsigned)cdiv64(p.N, 16 * NWV), (unsigned)S);
+  w4a16_xs_kernel<T, MT, NWV><<<grid, NWV * 64, lds, st>>>(p, slab, S, ppw);
+  if (S > 1) w4_reduce_kernel<T><<<(unsigned)cdiv64(p.M * (p.N / 4), 256), 256, 0, st>>>(p, slab, S);
+}
+
+// returns false when the shape / workspace does not allow this path
+template <typename T>
+static bool try_w4_xs(const W4Params& p, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (p.M > 128 || p.perm || p.group % 128 != 0) return false;
+  int S, ppw;
+  w4_plan(p.N, p.K, &S, &ppw);
+  const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
+  if (need > workspace_bytes || (need > 0 && !workspace)) {
+    if (p.K / 128 > 32) return false;      // cannot hold the whole k-range's zs words without split-K
+    S = 1;
+    ppw = (int)(p.K / 128);
+  }
+  float* slab = (float*)workspace;
+  if (p.M <= 16) launch_w4_xs<T, 1>(p, slab, S, ppw, st);
+  else if (p.M <= 32) launch_w4_xs<T, 2>(p, slab, S, ppw, st);
+  else if (p.M <= 64) launch_w4_xs<T, 4>(p, slab, S, ppw, st);
+  else launch_w4_xs<T, 8>(p, slab, S, ppw, st);
+  return true;
+}
+
 template <typename T, bool PERM> static void launch_w4(const W4Params& p, hipStream_t st) {
   const unsigned gx = (unsigned)cdiv64(p.N, 64);
   if (p.M <= 16) w4a16_gemm_kernel<T, 1, PERM><<<dim3(gx, (unsigned)cdiv64(p.M, 16)), 256, 0, st>>>(p);
@@ -215,7 +388,8 @@ template <typename T, bool PERM> static void launch_w4(const W4Params& p, hipStr
 
 extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native, const int32_t* perm,
                              const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t group_size,
-                             int64_t ldx, int64_t ldo, int dtype, void* stream) {
+                             int64_t ldx, int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
   MI_CHECK_ARG(M >= 0 && N > 0 && K > 0);
   if (M == 0) return MI_OK;
   MI_CHECK_ARG(x && qw_native && zs_native && out);
@@ -228,9 +402,12 @@ extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* z
   p.x = x; p.qw = (const uint32_t*)qw_native; p.zs = (const uint32_t*)zs_native; p.perm = perm;
   p.bias = bias; p.out = out; p.M = M; p.N = N; p.K = K; p.group = group_size; p.ldx = ldx; p.ldo = ldo;
   hipStream_t st = (hipStream_t)stream;
+  MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
   if (dtype == MI_FP16) {
+    if (try_w4_xs<f16_t>(p, workspace, workspace_bytes, st)) { MI_CHECK_LAUNCH(); return MI_OK; }
     if (perm) launch_w4<f16_t, true>(p, st); else launch_w4<f16_t, false>(p, st);
   } else {
+    if (try_w4_xs<bf16_t>(p, workspace, workspace_bytes, st)) { MI_CHECK_LAUNCH(); return MI_OK; }
     if (perm) launch_w4<bf16_t, true>(p, st); else launch_w4<bf16_t, false>(p, st);
   }
   MI_CHECK_LAUNCH();

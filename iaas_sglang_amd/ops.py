@@ -241,8 +241,11 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, grou
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    ws_bytes = lib.mi_w4a16_gemm_workspace_bytes(M, N, K) if perm is None else 0
+    ws = _gemm_workspace(ws_bytes, x.device) if ws_bytes else None
     check(lib.mi_w4a16_gemm(_ptr(x), _ptr(qw), _ptr(zs), _ptr(perm), _ptr(bias), _ptr(out), M, N, K,
-                            int(group_size), x.stride(0), out.stride(0), _dt(x), _stream()), "mi_w4a16_gemm")
+                            int(group_size), x.stride(0), out.stride(0), _dt(x), _ptr(ws),
+                            ws_bytes if ws is not None else 0, _stream()), "mi_w4a16_gemm")
     return out
 
 

@@ -168,7 +168,9 @@ int mi_w4_repack(const int32_t* qweight, const int32_t* qzeros, const void* scal
 int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native,
                   const int32_t* perm /* nullable */, const void* bias /* nullable */, void* out,
                   int64_t M, int64_t N, int64_t K, int64_t group_size, int64_t ldx, int64_t ldo,
-                  int dtype, void* stream);
+                  int dtype, void* workspace /* nullable */, int64_t workspace_bytes, void* stream);
+/* bytes of split-K scratch mi_w4a16_gemm can use (0: none needed); less is correct but slower */
+int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* W[K,N] = dequant(checkpoint-layout qweight) in `dtype` (unfused form, for tests and tools).
  * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221. */
