@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void fp8_gemm_skinny_kernel(const GemmPara
     const int64_t kb_ = (int64_t)(c_) * 128;                \
     W0 = *(const uint4*)(wp + kb_);                         \
     W1 = *(const uint4*)(wp + kb_ + 64);                    \
-    const int64_t kx_ = p.rotate == 2 ? 0 : kb_;            \
+    const int64_t kx_ = kb_;                                \
     _Pragma("unroll") for (int t = 0; t < MT; ++t) {        \
       X0[t] = *(const uint4*)(xp[t] + kx_);                 \
       X1[t] = *(const uint4*)(xp[t] + kx_ + 64);            \
@@ -633,7 +633,7 @@ template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_
 
 template <typename OutT>
 static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
-  if (p.M <= 128 && p.K % 128 == 0 && p.rotate != 3) {  // decode shapes: x-stationary, weights streamed once
+  if (p.M <= 128 && p.K % 128 == 0) {  // decode shapes: x-stationary, weights streamed once
     int S, spw;
     xs_plan(p.N, p.K, &S, &spw);
     const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
@@ -655,7 +655,7 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     else launch_skinny<OutT, 8>(p, st);
     return;
   }
-  if (p.K % 128 == 0 && p.rotate != 4) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
+  if (p.K % 128 == 0) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
     launch_tile<OutT>(p, st);
     return;
   }

@@ -334,3 +334,49 @@ def test_extend_len1_equals_decode():
     out_d = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
     o_.decode_attention(q.to(DEV), kca.to(DEV), vca.to(DEV), out_d, indptr, idx, D ** -0.5)
     torch.testing.assert_close(out_e.float(), out_d.cpu().float(), atol=4e-3, rtol=2 ** -6)
+
+
+@pytest.mark.parametrize("page_size", [16, 64])
+def test_decode_and_extend_with_paged_slots(page_size):
+    """page_size > 1 (test_flashattn_backend.py:324-346 cases): the allocator hands out page-aligned
+    runs of slots, req_to_token still holds one slot id per token, so the token-granular kernels
+    must give the same answers.  Slots here: request i owns whole pages, pages in random order."""
+    o_ = ops()
+    g = torch.Generator().manual_seed(page_size)
+    Hq, Hkv, D, dtype = 32, 8, 128, torch.bfloat16
+    lens = [1, page_size - 1, page_size, page_size + 1, 3 * page_size + 7, 200]
+    pages_needed = [-(-L // page_size) for L in lens]
+    n_pages = sum(pages_needed)
+    page_order = torch.randperm(n_pages, generator=g) + 1          # page 0 is the padding page
+    slots = (n_pages + 1) * page_size
+    k = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    B = len(lens)
+    r2t = torch.zeros(B, max(lens) + 1, dtype=torch.int32)
+    off = 0
+    for i, L in enumerate(lens):
+        pg = page_order[off: off + pages_needed[i]]
+        off += pages_needed[i]
+        tok = (pg[:, None] * page_size + torch.arange(page_size)[None, :]).reshape(-1)[:L]
+        r2t[i, :L] = tok.to(torch.int32)
+    rpi = torch.arange(B, dtype=torch.int64)
+    sl = torch.tensor(lens, dtype=torch.int64)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    indptr = o_.kv_indptr(sl.to(DEV))
+    idx = torch.empty(sum(lens), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t.to(DEV), rpi.to(DEV), sl.to(DEV), indptr, idx)
+    out = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+    ws = torch.empty(o_.decode_workspace_numel(B, Hq, D, 4), dtype=torch.float32, device=DEV)
+    o_.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), out, indptr, idx, D ** -0.5, 0.0, 4, ws)
+    ref = oa.decode_fp32(q, k, v, r2t, rpi, sl, scaling=D ** -0.5)
+    torch.testing.assert_close(out.cpu().float(), ref, **_tol(dtype))
+    # extend: half of every request cached (page-aligned prefix slots), half new
+    pre = torch.tensor([L // 2 for L in lens])
+    ext = torch.tensor([L - L // 2 for L in lens])
+    E = int(ext.sum())
+    qe = torch.randn(E, Hq, D, generator=g).to(dtype)
+    kn = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    vn = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    oute, kca, vca = _run_extend(None, qe, kn, vn, k, v, r2t, rpi, pre, ext, D ** -0.5, True)
+    refe = oa.extend_fp32(qe, kca, vca, r2t, rpi, sl, pre, ext, scaling=D ** -0.5)
+    torch.testing.assert_close(oute.float(), refe, atol=4e-3, rtol=2 ** -6)

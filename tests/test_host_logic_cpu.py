@@ -1,0 +1,99 @@
+"""CPU-only tests of the host-side plugin logic (no kernels are launched)."""
+import types
+
+import pytest
+import torch
+
+from iaas_sglang_amd import _compat
+from iaas_sglang_amd.quantization import (AWQConfig, AWQLinearMethod, Fp8Config, Fp8LinearMethod, GPTQConfig,
+                                          GPTQLinearMethod, MI_QUANTIZATION_METHODS)
+
+
+def test_forward_mode_predicates_match_reference_table():
+    # python/sglang/srt/model_executor/forward_batch_info.py:60-123
+    FM = _compat.ForwardMode
+    assert FM.DECODE.is_decode() and not FM.DECODE.is_extend() and FM.DECODE.is_cuda_graph()
+    for m in (FM.EXTEND, FM.MIXED, FM.DRAFT_EXTEND, FM.TARGET_VERIFY):
+        assert m.is_extend() and not m.is_decode()
+    assert FM.IDLE.is_decode_or_idle() and FM.IDLE.is_cuda_graph() and not FM.EXTEND.is_cuda_graph()
+
+
+def test_quant_registry_and_config_parsing():
+    assert set(MI_QUANTIZATION_METHODS) == {"fp8", "awq", "gptq"}
+    c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static", "ignored_layers": ["lm_head"]})
+    assert c.is_checkpoint_fp8_serialized and c.activation_scheme == "static" and c.get_name() == "fp8"
+    assert c.get_min_capability() <= 95 and torch.bfloat16 in c.get_supported_act_dtypes()
+    with pytest.raises(ValueError):
+        Fp8Config(activation_scheme="bogus")
+    with pytest.raises(NotImplementedError):
+        Fp8Config(is_checkpoint_fp8_serialized=True, weight_block_size=[128, 128])   # block-fp8 is out of scope
+    a = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    assert a.pack_factor == 8 and a.get_name() == "awq"
+    with pytest.raises(ValueError):
+        AWQConfig(8, 128, True)
+    g = GPTQConfig.from_config({"bits": 4, "group_size": 128, "desc_act": True})
+    assert g.desc_act and g.get_name() == "gptq"
+    # class names the reference's WEIGHT_LOADER_V2_SUPPORTED list keys on (layers/linear.py:42-60)
+    assert [k.__name__ for k in (Fp8LinearMethod, AWQLinearMethod, GPTQLinearMethod)] == \
+        ["Fp8LinearMethod", "AWQLinearMethod", "GPTQLinearMethod"]
+
+
+def test_create_weights_shapes_follow_the_reference_contract():
+    layer = torch.nn.Module()
+    Fp8LinearMethod(Fp8Config(True, "static")).create_weights(layer, 256, [128, 64, 64], 256, 256, torch.bfloat16,
+                                                              weight_loader=None)
+    assert layer.weight.shape == (256, 256) and layer.weight.dtype == torch.float8_e4m3fn      # fp8.py:267-278
+    assert layer.weight_scale.shape == (3,) and layer.input_scale.shape == (3,)               # :294-320
+    assert float(layer.weight_scale[0]) == torch.finfo(torch.float32).min
+    layer = torch.nn.Module()
+    AWQLinearMethod(AWQConfig(4, 128, True)).create_weights(layer, 256, [512], 256, 512, torch.float16,
+                                                            weight_loader=None)
+    assert layer.qweight.shape == (256, 64) and layer.qzeros.shape == (2, 64) and layer.scales.shape == (2, 512)
+    assert layer.qweight.packed_dim == 1 and layer.qweight.packed_factor == 8                  # awq.py:140-151
+    with pytest.raises(ValueError):
+        AWQLinearMethod(AWQConfig(4, 128, True)).create_weights(torch.nn.Module(), 200, [512], 200, 512,
+                                                                torch.float16, weight_loader=None)
+    layer = torch.nn.Module()
+    GPTQLinearMethod(GPTQConfig(4, 128, False)).create_weights(layer, 256, [512], 256, 512, torch.float16,
+                                                               weight_loader=None)
+    assert layer.qweight.shape == (32, 512) and layer.g_idx.shape == (256,)
+
+
+def _fake_runner(hq=32, hkv=8, d=128, ctx=4096, max_reqs=16):
+    pool = types.SimpleNamespace(get_value_buffer=lambda i: torch.empty(1, hkv, d), get_key_buffer=lambda i: None)
+    mc = types.SimpleNamespace(num_attention_heads=hq, context_len=ctx, get_num_kv_heads=lambda tp: hkv // tp)
+    sa = types.SimpleNamespace(triton_attention_num_kv_splits=8)
+    return types.SimpleNamespace(device="cpu", req_to_token_pool=types.SimpleNamespace(
+        size=max_reqs, req_to_token=torch.zeros(max_reqs, ctx, dtype=torch.int32)), token_to_kv_pool=pool,
+        model_config=mc, server_args=sa, sliding_window_size=None, tp_size=1)
+
+
+def test_backend_split_heuristic_and_contract(monkeypatch):
+    from iaas_sglang_amd import attention_backend as ab
+    monkeypatch.setattr(ab.ops, "cu_count", lambda: 256)
+    be = ab.MiAttnBackend(_fake_runner())
+    assert be.get_cuda_graph_seq_len_fill_value() == 1 and be.support_triton() is False
+    assert be._choose_splits(128, 128 * 2048) == 4          # 1024 (b, kv-head) waves -> 4 splits fill 256 CUs x 16
+    assert be._choose_splits(1, 100) == 1                    # never split below ~256 keys
+    assert be._choose_splits(1, 100000) == 8                 # capped by --triton-attention-num-kv-splits
+    assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
+    fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.TARGET_VERIFY, spec_info=None)
+    with pytest.raises(NotImplementedError):
+        be.init_forward_metadata(fb)                          # speculative modes: out of scope, loud
+    r = _fake_runner()
+    r.sliding_window_size = 4096
+    with pytest.raises(NotImplementedError):
+        ab.MiAttnBackend(r)
+
+
+def test_register_is_a_noop_without_sglang():
+    from iaas_sglang_amd import register as reg
+    if not _compat.HAVE_SGLANG:
+        assert reg.register() is False
+
+
+def test_ops_refuse_cpu_tensors():
+    from iaas_sglang_amd import ops
+    from iaas_sglang_amd._lib import MiHotpathError
+    with pytest.raises(MiHotpathError):
+        ops.kv_indptr(torch.tensor([1, 2, 3]))               # no CPU path exists in the product
