@@ -28,6 +28,8 @@ SIGNATURES = {
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _f, _f, _i64, _int, _p]),
+    "mi_decode_attn_fp8out": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                     _f, _f, _i64, _int, _p]),
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_merge_state": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
@@ -53,6 +55,12 @@ SIGNATURES = {
     "mi_silu_and_mul_fp8": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_rope_neox": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_silu_and_mul": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_fp8_gemm_fused_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "mi_fp8_gemm_add_rmsnorm_fp8": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int,
+                                           _p, _i64, _p]),
+    "mi_fp8_gemm_rope_kvwrite": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,
+                                        _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
+    "mi_fp8_gemm_silu_mul_fp8": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mi_w4_dequantize": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
 }
 

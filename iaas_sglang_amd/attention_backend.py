@@ -145,15 +145,24 @@ class MiAttnBackend(AttentionBackend):
             raise NotImplementedError("MiAttnBackend: fp8 KV cache (k_scale/v_scale) is a later row (SURVEY 8f-1)")
         ops.kv_write(k_buf, v_buf, forward_batch.out_cache_loc, k, v)
 
-    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True, fp8_out_scale=None):
+        """`fp8_out_scale` (extension, passed through AttentionBackend.forward's **kwargs): the static input
+        scale of the following FP8 linear; the output is then returned already quantised (fp8), bit-identical
+        to quantising the bf16 result -- the merge stage writes it directly."""
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("MiAttnBackend: qk_head_dim != v_head_dim (MLA) is out of scope")
-        o = q.new_empty(q.shape)
         if save_kv_cache:
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
+        if fp8_out_scale is not None:
+            o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
+            ops.decode_attention_fp8out(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf, o8,
+                                        fp8_out_scale, md.kv_indptr, md.kv_indices, layer.scaling,
+                                        getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace)
+            return o8
+        o = q.new_empty(q.shape)
         ops.decode_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf,
                              o.view(-1, layer.tp_q_head_num, layer.v_head_dim), md.kv_indptr, md.kv_indices,
                              layer.scaling, getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace)

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MI_WAVE 64
+// cross-file helpers that are NOT part of the C ABI (not exported from libmi_hotpath.so)
+#define MI_INTERNAL extern "C" __attribute__((visibility("hidden")))
 
 // ---- error plumbing (host) --------------------------------------------------
 void mi_set_error(const char* fmt, ...);
@@ -61,8 +63,18 @@ template <> struct Elem<f16_t> {
 };
 
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  asm volatile("" : "+v"(a), "+v"(b));   // fp32 values first, then ONE conversion each (see round_to below)
   T x = (T)a, y = (T)b;
   return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+// fp32 -> T -> fp32 with the fp32 value materialised first: without the (empty) asm hipcc folds a preceding
+// fp32 multiply into v_fma_mixlo_f16, which rounds the exact product ONCE to f16 -- the unfused sequence
+// (and the reference's torch ops) round to fp32 first, then to f16; the two differ in rare double-rounding
+// cases (measured: 28 of 524,288 q values after RoPE).  Fused kernels that promise bit-identity use this.
+template <typename T> __device__ __forceinline__ float round_to(float v) {
+  asm volatile("" : "+v"(v));
+  return (float)(T)v;
 }
 
 // broadcast lane `N` of each 16-lane row to the whole row (gfx90a+ DPP row_newbcast)

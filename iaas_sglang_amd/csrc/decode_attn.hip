@@ -31,7 +31,18 @@ struct DecodeParams {
   int64_t stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot;
   float scale_log2;  // sm_scale * log2(e)   (logit_cap == 0)
   float sm_scale, logit_cap;
+  uint8_t* o_q;          // optional fp8 copy of o, [B][Hq*D] contiguous, = quant(T-rounded o, *o_qscale)
+  const float* o_qscale;
 };
+
+// T-rounded values -> e4m3fn with a static scale (same arithmetic as quant_tensor_kernel mode 1)
+template <typename T> __device__ __forceinline__ uint32_t quant4_static(float a, float b, float c, float d, float inv) {
+  auto f = [inv](float v) { return fmaxf(fminf(round_to<T>(v) * inv, 448.0f), -448.0f); };
+  uint32_t w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f(a), f(b), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f(c), f(d), w, true);
+  return w;
+}
 
 #define RESCALE_THR 8.0f
 
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams 
     } else if (row == 0 && col < LPT) {
       for (int g = 0; g < group; ++g) {
         T* o = (T*)p.o + (int64_t)b * p.stride_o_tok + (int64_t)(hq0 + g) * D + col * 8;
-        *(uint4*)o = make_uint4(0, 0, 0, 0);
+        if (p.o) *(uint4*)o = make_uint4(0, 0, 0, 0);
+        if (p.o_q) *(uint2*)(p.o_q + ((int64_t)b * p.num_q_heads + hq0 + g) * D + col * 8) = make_uint2(0, 0);
       }
     }
     return;
@@ -249,7 +261,15 @@ __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams 
         out.y = pack2<T>(acc[g][2] * inv, acc[g][3] * inv);
         out.z = pack2<T>(acc[g][4] * inv, acc[g][5] * inv);
         out.w = pack2<T>(acc[g][6] * inv, acc[g][7] * inv);
-        *(uint4*)((T*)p.o + (int64_t)b * p.stride_o_tok + hq * D + col * 8) = out;
+        if (p.o) *(uint4*)((T*)p.o + (int64_t)b * p.stride_o_tok + hq * D + col * 8) = out;
+        if (p.o_q) {
+          const float qs = *p.o_qscale;
+          const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+          uint2 w;
+          w.x = quant4_static<T>(acc[g][0] * inv, acc[g][1] * inv, acc[g][2] * inv, acc[g][3] * inv, qinv);
+          w.y = quant4_static<T>(acc[g][4] * inv, acc[g][5] * inv, acc[g][6] * inv, acc[g][7] * inv, qinv);
+          *(uint2*)(p.o_q + ((int64_t)b * p.num_q_heads + hq) * D + col * 8) = w;
+        }
       } else {
         const int64_t slot = ((int64_t)b * p.num_q_heads + hq) * nsplit + s;
         float4* wo = (float4*)(p.ws_o + slot * D + col * 8);
@@ -269,7 +289,8 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ ws_o,
                                                            const float* __restrict__ ws_ml, T* o,
                                                            int64_t n_bh, int32_t num_q_heads,
-                                                           int32_t nsplit, int64_t stride_o_tok) {
+                                                           int32_t nsplit, int64_t stride_o_tok,
+                                                           uint8_t* __restrict__ o_q, const float* __restrict__ o_qscale) {
   constexpr int EPL = D / 64 > 0 ? D / 64 : 1;  // elements per lane
   const int lane = threadIdx.x & 63;
   const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -294,10 +315,24 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   }
   if (active) {
     const int64_t b = bh / num_q_heads, h = bh % num_q_heads;
-    T* out = o + b * stride_o_tok + h * D + lane * EPL;
     const float inv = 1.f / L;
+    if (o) {
+      T* out = o + b * stride_o_tok + h * D + lane * EPL;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) out[e] = (T)(acc[e] * inv);
+      for (int e = 0; e < EPL; ++e) out[e] = (T)round_to<T>(acc[e] * inv);
+    }
+    if (o_q) {
+      const float qs = *o_qscale;
+      const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+      uint8_t* out = o_q + bh * D + lane * EPL;
+      if constexpr (EPL == 2) {
+        const uint32_t w = quant4_static<T>(acc[0] * inv, acc[1] * inv, 0.f, 0.f, qinv);
+        *(uint16_t*)out = (uint16_t)(w & 0xffffu);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) out[e] = (uint8_t)(quant4_static<T>(acc[e] * inv, 0.f, 0.f, 0.f, qinv) & 0xffu);
+      }
+    }
   }
 }
 
@@ -345,15 +380,17 @@ static int launch_decode_g(const DecodeParams& p, int64_t batch, hipStream_t st)
   return MI_OK;
 }
 
-extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
-                              const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
-                              int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
-                              int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
-                              int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                              float logit_cap, int64_t num_splits, int dtype, void* stream) {
+static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf, void* o,
+                            const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
+                            int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                            int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                            int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                            float logit_cap, int64_t num_splits, int dtype, void* stream, void* o_fp8,
+                            const float* o_scale) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
-  MI_CHECK_ARG(q && k_buf && v_buf && o && kv_indptr && kv_indices);
+  MI_CHECK_ARG(q && k_buf && v_buf && (o || o_fp8) && kv_indptr && kv_indices);
+  MI_CHECK_ARG(!o_fp8 || (o_scale && ((uintptr_t)o_fp8 & 7) == 0));
   MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
   MI_CHECK_ARG(num_splits >= 1 && num_splits <= 65535 && batch <= 65535);
   MI_CHECK_ARG(num_splits == 1 || workspace != nullptr);
@@ -377,6 +414,7 @@ extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_bu
   p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
   p.sm_scale = sm_scale; p.logit_cap = logit_cap;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.o_q = (uint8_t*)o_fp8; p.o_qscale = o_scale;
   hipStream_t st = (hipStream_t)stream;
 
   int rc;
@@ -392,16 +430,40 @@ extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_bu
     const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
     if (dtype == MI_BF16) {
       if (head_dim == 128)
-        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
       else
-        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
     } else {
       if (head_dim == 128)
-        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
       else
-        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok);
+        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
     }
     MI_CHECK_LAUNCH();
   }
   return MI_OK;
+}
+
+extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
+                              const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
+                              int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                              int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                              int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                              float logit_cap, int64_t num_splits, int dtype, void* stream) {
+  MI_CHECK_ARG(o != nullptr);
+  return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stream, nullptr, nullptr);
+}
+
+extern "C" int mi_decode_attn_fp8out(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                                     void* o_fp8, const float* o_scale, const int32_t* kv_indptr,
+                                     const int32_t* kv_indices, void* workspace, int64_t batch, int64_t num_q_heads,
+                                     int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                                     int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
+                                     int64_t num_splits, int dtype, void* stream) {
+  MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr);
+  return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stream, o_fp8, o_scale);
 }

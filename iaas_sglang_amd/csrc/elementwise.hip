@@ -4,7 +4,7 @@
 // All 16-byte vector loads/stores; HBM/L2-bound, no MFMA.
 #include "common.h"
 
-template <typename T> __device__ __forceinline__ float rnd(float v) { return (float)(T)v; }
+template <typename T> __device__ __forceinline__ float rnd(float v) { return round_to<T>(v); }
 
 template <typename T> __device__ __forceinline__ void unpack8f(const uint4& u, float (&f)[8]) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};

@@ -261,9 +261,18 @@ static void launch_skinny(const GemmParams& p, hipStream_t st) {
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales; one `vmcnt(0)` + barrier per phase.
 // S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to slab[sp][M][N], summed by
 // fp8_gemm_reduce_kernel.
-template <typename OutT, int MT, int NWV, int NST>   // NST = LDS ring depth (2 or 3 stages)
+// EPI = 1 (gate_up of a gated MLP, N = 2*I, S == 1, NWV == 8): waves 0-3 own four 16-row GATE tiles, waves
+// 4-7 the UP tiles of the same output columns; the epilogue exchanges the up values through LDS and writes
+// fp8(silu(gate) * up) [M, I] with the static scale *q_scale -- bit-identical to the bf16 GEMM output
+// followed by mi_silu_and_mul_fp8 (activation.py:56-58 + static quant), without the [M, 2I] round trip.
+struct SiluEpi {
+  uint8_t* q_out;
+  const float* q_scale;
+};
+template <typename OutT, int MT, int NWV, int NST, int EPI = 0>   // NST = LDS ring depth (2 or 3 stages)
 __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
-                                                               int S, int phases_per_wg) {
+                                                               int S, int phases_per_wg, int force_slab,
+                                                               const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
   constexpr int PW = 256;                       // phase width (bytes of K) = 2 MFMA k-chunks
   constexpr int ROWS = MT * 16;
   constexpr int XBYTES = ROWS * PW;             // x block of one stage
@@ -271,13 +280,15 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int64_t n0 = ((int64_t)blockIdx.x * NWV + wave) * 16;
+  const int64_t Ihalf = p.N / 2;                // EPI only
+  const int64_t c0 = ((int64_t)blockIdx.x * (NWV / 2) + (wave & (NWV / 2 - 1))) * 16;   // EPI: output column of the tile
+  const int64_t n0 = EPI ? (wave < NWV / 2 ? c0 : Ihalf + c0) : ((int64_t)blockIdx.x * NWV + wave) * 16;
   const int sp = blockIdx.y;
   const int64_t KC = p.K / 128;                 // K % 128 == 0 on this path
   const int64_t NPH = (KC + 1) / 2;
   const int64_t ph0 = (int64_t)sp * phases_per_wg;
   const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
-  const bool tile_ok = n0 < p.N;
+  const bool tile_ok = EPI ? c0 < Ihalf : n0 < p.N;
   const uint32_t lds_base = lds_addr_of(smem);
 
   f32x4 acc[MT];
@@ -377,10 +388,54 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
 #undef XS_BARRIER_AFTER
 #undef XS_STAGE
 #undef XS_MMA
+  if constexpr (EPI == 1) {
+    // every wave is past the last phase barrier: the stages are free.  up waves publish round_T(acc*sa*sb+bias)
+    f32x4* xch = (f32x4*)smem;                  // [NWV/2][MT][64] f32x4
+    float sbv[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = min(n0 + 4 * q + r, p.N - 1);
+      sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+      bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int64_t m = min((int64_t)t * 16 + r16, p.M - 1);
+      const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = round_to<OutT>(acc[t][r] * sav * sbv[r] + bv[r]);
+    }
+    if (wave >= NWV / 2) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xch[((wave - NWV / 2) * MT + t) * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave >= NWV / 2 || !tile_ok) return;
+    const float qs = *epi.q_scale;
+    const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int64_t m = (int64_t)t * 16 + r16;
+      if (m >= p.M) continue;
+      const f32x4 u = xch[(wave * MT + t) * 64 + lane];
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g = acc[t][r];
+        o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+        o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+      }
+      uint32_t w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+      *(uint32_t*)(epi.q_out + m * Ihalf + c0 + 4 * q) = w;
+    }
+    return;
+  }
   if (!tile_ok) return;
 
   const int64_t nb = n0 + 4 * q;
-  if (S > 1) {  // fp32 partial tile -> slab[sp][m][n]
+  if (S > 1 || force_slab) {  // fp32 partial tile -> slab[sp][m][n]
     float* sb = slab + (int64_t)sp * p.M * p.N;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -481,15 +536,16 @@ static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
 }
 
 template <typename OutT, int MT>
-static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st) {
+static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false) {
   const int nw = xs_waves(p.N);
   static const int nst4 = xs_env("MI_GEMM_XS_STAGES", 3);
   const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
   dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
-  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw);
-  else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw);
-  else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw);
-  if (S > 1) {
+  const int fs = partial ? 1 : 0;
+  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
+  else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw, fs);
+  else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw, fs);
+  if (S > 1 && !partial) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, slab, S);
   }
@@ -693,6 +749,65 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
   MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
   if (out_dtype == MI_BF16) launch_fp8_gemm<bf16_t>(p, st, workspace, workspace_bytes);
   else launch_fp8_gemm<f16_t>(p, st, workspace, workspace_bytes);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ---- split-K partial form: raw fp32 accumulators, no epilogue; a fused consumer (fused_glue.hip)
+// sums the slabs and applies scales / residual / norm / rope itself.
+MI_INTERNAL int mi_fp8_gemm_plan_splits(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || M > 128 || K % 128 != 0) return 0;   // 0: the partial form does not apply
+  int S, ppw;
+  xs_plan(N, K, &S, &ppw);
+  return S;
+}
+
+MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slabs, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldb, void* stream) {
+  MI_CHECK_ARG(a && b_nk && slabs && M > 0 && M <= 128 && N > 0 && K > 0);
+  if (K % 128 != 0 || lda % 16 != 0 || ldb % 16 != 0 || N % 4 != 0)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_partial: need K%%128==0, N%%4==0, lda/ldb%%16==0");
+  MI_CHECK_ARG((((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)slabs) & 15) == 0);
+  GemmParams p;
+  p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = nullptr; p.sb = nullptr; p.bias = nullptr; p.out = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = 0;
+  int S, ppw;
+  xs_plan(N, K, &S, &ppw);
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 16) launch_xs<bf16_t, 1>(p, slabs, S, ppw, st, true);
+  else if (M <= 32) launch_xs<bf16_t, 2>(p, slabs, S, ppw, st, true);
+  else if (M <= 64) launch_xs<bf16_t, 4>(p, slabs, S, ppw, st, true);
+  else launch_xs<bf16_t, 8>(p, slabs, S, ppw, st, true);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ---- gate_up GEMM with the SiLU*mul + static FP8 quant epilogue (EPI = 1).  Returns 1 when the shape is not
+// eligible (split-K wanted, narrow N, M tile) so that the caller takes the slab route instead.
+MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                          void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K, int64_t lda,
+                                          int64_t ldb, int dtype, void* stream) {
+  const int64_t N = 2 * I;
+  if (M <= 0 || M > 128 || K % 128 != 0 || I % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0) return 1;
+  if ((((uintptr_t)a | (uintptr_t)b_nk) & 15) || ((uintptr_t)q_out & 3)) return 1;
+  if (xs_waves(N) != 8) return 1;
+  int S, ppw;
+  xs_plan(N, K, &S, &ppw);
+  if (S != 1) return 1;
+  GemmParams p;
+  p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = 0;
+  const SiluEpi epi{(uint8_t*)q_out, q_scale};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(I / 64), 1);
+#define LAUNCH_EPI(TT, MTV)                                                                                    \
+  fp8_gemm_xs_kernel<TT, MTV, 8, 2, 1><<<grid, 512, 2 * (size_t)(MTV * 16 + 128) * 256, st>>>(p, nullptr, 1, ppw, 0, epi)
+  if (dtype == MI_BF16) {
+    if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else LAUNCH_EPI(bf16_t, 8);
+  } else {
+    if (M <= 16) LAUNCH_EPI(f16_t, 1); else if (M <= 32) LAUNCH_EPI(f16_t, 2); else if (M <= 64) LAUNCH_EPI(f16_t, 4); else LAUNCH_EPI(f16_t, 8);
+  }
+#undef LAUNCH_EPI
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

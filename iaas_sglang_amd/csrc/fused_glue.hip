@@ -1,0 +1,291 @@
+// Fused consumers of split-K slabs (widened): the FP8 decode GEMM leaves
+// raw fp32 accumulators in S slabs [S][M][N]; these kernels sum them, apply the GEMM's own epilogue
+// (x = round_T(sum * sa * sb)) and then the next op(s) of the layer in the same pass, removing the
+// standalone reduce / rope / kv-write / norm / quant launches (each ~5 us at M = 128).
+// Every rounding of the unfused sequence is reproduced, so results are bit-identical to it.
+// Public entry points (include/mi_hotpath.h): mi_fp8_gemm_add_rmsnorm_fp8, mi_fp8_gemm_rope_kvwrite,
+// mi_fp8_gemm_silu_mul_fp8 = partial GEMM (fp8_gemm.hip) + one consumer launch.
+#include "common.h"
+
+MI_INTERNAL int mi_fp8_gemm_plan_splits(int64_t M, int64_t N, int64_t K);
+MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slabs, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldb, void* stream);
+MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                         void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K, int64_t lda,
+                                         int64_t ldb, int dtype, void* stream);   // rc 1 = shape not eligible
+
+template <typename T> __device__ __forceinline__ float rndT(float v) { return round_to<T>(v); }
+
+template <typename T> __device__ __forceinline__ void unpack8g(const uint4& u, float (&f)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = Elem<T>::lo(w[j]); f[2 * j + 1] = Elem<T>::hi(w[j]); }
+}
+template <typename T> __device__ __forceinline__ uint4 pack8g(const float (&f)[8]) {
+  return make_uint4(pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3]), pack2<T>(f[4], f[5]), pack2<T>(f[6], f[7]));
+}
+__device__ __forceinline__ uint2 quant8g(const float (&f)[8], float inv) {
+  uint32_t lo = 0, hi = 0;
+  auto c = [](float v) { return fmaxf(fminf(v, 448.0f), -448.0f); };
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[0] * inv), c(f[1] * inv), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[2] * inv), c(f[3] * inv), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[4] * inv), c(f[5] * inv), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[6] * inv), c(f[7] * inv), hi, true);
+  return make_uint2(lo, hi);
+}
+
+// ------------------------------------------------ slabs -> (+residual) -> RMSNorm -> fp8
+// == fp8_gemm reduce epilogue, then RMSNorm.forward_native with residual (layernorm.py:128-146),
+// then static per-tensor quant.  One workgroup per row.
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* __restrict__ slab, int S,
+                                                                   const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                   T* __restrict__ residual, const T* __restrict__ w,
+                                                                   uint8_t* __restrict__ q_out, const float* __restrict__ q_scale,
+                                                                   T* __restrict__ out, int64_t M, int64_t H, float eps) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int64_t nvec = H / 8;
+  float v[VPT][8];
+  float ss = 0.f;
+  // slab sum in split order, then the GEMM epilogue exactly as fp8_gemm_reduce_kernel does it
+  // (acc * sa * sb, one rounding to T), then the residual add in fp32
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t c = threadIdx.x + i * 256;
+    if (c < nvec) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const f32x4 a = *(const f32x4*)(slab + (s * M + row) * H + c * 8);
+        const f32x4 b = *(const f32x4*)(slab + (s * M + row) * H + c * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = rndT<T>(acc[j] * sa[0] * sb[0]);
+      if (residual) {
+        float r[8];
+        unpack8g<T>(*(const uint4*)(residual + row * H + c * 8), r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] += r[j];
+        *(uint4*)(residual + row * H + c * 8) = pack8g<T>(v[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  ss = red[0] + red[1] + red[2] + red[3];
+  const float inv = rsqrtf(ss / (float)H + eps);
+  float qinv = 0.f;
+  if (q_out) {
+    const float qs = *q_scale;
+    qinv = qs > 0.f ? 1.0f / qs : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t c = threadIdx.x + i * 256;
+    if (c < nvec) {
+      float wf[8], o[8];
+      unpack8g<T>(*(const uint4*)(w + c * 8), wf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rndT<T>(v[i][j] * inv * wf[j]);
+      if (out) *(uint4*)(out + row * H + c * 8) = pack8g<T>(o);
+      if (q_out) *(uint2*)(q_out + row * H + c * 8) = quant8g(o, qinv);
+    }
+  }
+}
+
+static int slab_add_rmsnorm_fp8(const float* slab, int S, const float* scale_a, const float* scale_b,
+                                void* residual, const void* weight, void* q_out, const float* q_scale,
+                                void* out, int64_t M, int64_t H, float eps, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int vpt = (int)cdiv64(H / 8, 256);
+#define LAUNCH(TT, V) slab_add_rmsnorm_fp8_kernel<TT, V><<<(unsigned)M, 256, 0, st>>>(slab, S, scale_a, scale_b, (TT*)residual, (const TT*)weight, (uint8_t*)q_out, q_scale, (TT*)out, M, H, eps)
+  if (dtype == MI_BF16) { if (vpt <= 1) LAUNCH(bf16_t, 1); else if (vpt <= 2) LAUNCH(bf16_t, 2); else if (vpt <= 4) LAUNCH(bf16_t, 4); else LAUNCH(bf16_t, 8); }
+  else { if (vpt <= 1) LAUNCH(f16_t, 1); else if (vpt <= 2) LAUNCH(f16_t, 2); else if (vpt <= 4) LAUNCH(f16_t, 4); else LAUNCH(f16_t, 8); }
+#undef LAUNCH
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ------------------------------------------------ slabs (qkv) -> RoPE -> q out + KV-pool write
+// == fp8_gemm reduce epilogue, RotaryEmbedding.forward_native (neox, rotary_embedding.py:49-166) on q,k
+// and set_kv_buffer (memory_pool.py:454-455).  One thread per 8 rotation pairs / 16 v elements.
+template <typename T>
+__global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __restrict__ slab, int S,
+                                                                const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                const int64_t* __restrict__ positions,
+                                                                const float* __restrict__ cos_sin, T* __restrict__ q_out,
+                                                                T* __restrict__ k_cache, T* __restrict__ v_cache,
+                                                                const int64_t* __restrict__ loc, int64_t tokens, int Hq,
+                                                                int Hkv, int D, int64_t ldq, int64_t cache_stride_k,
+                                                                int64_t cache_stride_v) {
+  const int half = D / 2, vph = half / 8;
+  const int heads = Hq + 2 * Hkv;
+  const int64_t N = (int64_t)heads * D;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_tok = (int64_t)heads * vph;
+  if (gid >= tokens * per_tok) return;
+  const int64_t t = gid / per_tok;
+  const int rem = (int)(gid % per_tok);
+  const int h = rem / vph, c = rem % vph;
+  const int64_t col = (int64_t)h * D + c * 8;
+  float acc1[8], acc2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
+  for (int s = 0; s < S; ++s) {
+    const float* base = slab + (s * tokens + t) * N + col;
+    const f32x4 a = *(const f32x4*)base, b = *(const f32x4*)(base + 4);
+    const f32x4 e = *(const f32x4*)(base + half), f = *(const f32x4*)(base + half + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc1[j] += a[j]; acc1[4 + j] += b[j]; acc2[j] += e[j]; acc2[4 + j] += f[j]; }
+  }
+  float x1[8], x2[8], o1[8], o2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x1[j] = rndT<T>(acc1[j] * sa[0] * sb[0]); x2[j] = rndT<T>(acc2[j] * sa[0] * sb[0]); }
+  if (h < Hq + Hkv) {  // q or k head: rotate
+    const float* cs = cos_sin + positions[t] * D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float co = rndT<T>(cs[c * 8 + j]), si = rndT<T>(cs[half + c * 8 + j]);
+      o1[j] = rndT<T>(rndT<T>(x1[j] * co) - rndT<T>(x2[j] * si));
+      o2[j] = rndT<T>(rndT<T>(x2[j] * co) + rndT<T>(x1[j] * si));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o1[j] = x1[j]; o2[j] = x2[j]; }
+  }
+  T* dst;
+  if (h < Hq) dst = q_out + t * ldq + (int64_t)h * D;
+  else if (h < Hq + Hkv) dst = k_cache + loc[t] * cache_stride_k + (int64_t)(h - Hq) * D;
+  else dst = v_cache + loc[t] * cache_stride_v + (int64_t)(h - Hq - Hkv) * D;
+  *(uint4*)(dst + c * 8) = pack8g<T>(o1);
+  *(uint4*)(dst + half + c * 8) = pack8g<T>(o2);
+}
+
+static int slab_rope_kvwrite(const float* slab, int S, const float* scale_a, const float* scale_b,
+                             const int64_t* positions, const float* cos_sin_cache, void* q_out, void* k_cache,
+                             void* v_cache, const int64_t* loc, int64_t tokens, int64_t num_q_heads,
+                             int64_t num_kv_heads, int64_t head_dim, int64_t ldq, int64_t cache_stride_k,
+                             int64_t cache_stride_v, int dtype, void* stream) {
+  const int64_t total = tokens * (num_q_heads + 2 * num_kv_heads) * (head_dim / 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_BF16)
+    slab_rope_kvwrite_kernel<bf16_t><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(slab, S, scale_a, scale_b, positions, cos_sin_cache, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, loc, tokens, (int)num_q_heads, (int)num_kv_heads, (int)head_dim, ldq, cache_stride_k, cache_stride_v);
+  else
+    slab_rope_kvwrite_kernel<f16_t><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(slab, S, scale_a, scale_b, positions, cos_sin_cache, (f16_t*)q_out, (f16_t*)k_cache, (f16_t*)v_cache, loc, tokens, (int)num_q_heads, (int)num_kv_heads, (int)head_dim, ldq, cache_stride_k, cache_stride_v);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ------------------------------------------------ slabs (gate_up) -> SiLU(gate) * up -> fp8
+// == fp8_gemm reduce epilogue, SiluAndMul.forward_native (activation.py:56-58), static per-tensor quant.
+template <typename T>
+__global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __restrict__ slab, int S,
+                                                                const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                uint8_t* __restrict__ q_out, const float* __restrict__ q_scale,
+                                                                int64_t M, int64_t I) {
+  const float qs = *q_scale;
+  const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+  const int64_t vpr = I / 8, N = 2 * I;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < M * vpr; gid += (int64_t)gridDim.x * 256) {
+    const int64_t r = gid / vpr, c = gid % vpr;
+    float g[8], u[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g[j] = 0.f; u[j] = 0.f; }
+    for (int s = 0; s < S; ++s) {
+      const float* base = slab + (s * M + r) * N + c * 8;
+      const f32x4 a = *(const f32x4*)base, b = *(const f32x4*)(base + 4);
+      const f32x4 e = *(const f32x4*)(base + I), f = *(const f32x4*)(base + I + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { g[j] += a[j]; g[4 + j] += b[j]; u[j] += e[j]; u[4 + j] += f[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gv = rndT<T>(g[j] * sa[0] * sb[0]), uv = rndT<T>(u[j] * sa[0] * sb[0]);
+      o[j] = rndT<T>(rndT<T>(gv / (1.f + expf(-gv))) * uv);
+    }
+    *(uint2*)(q_out + r * I + c * 8) = quant8g(o, qinv);
+  }
+}
+
+// ============================================================================ public entry points
+extern "C" int64_t mi_fp8_gemm_fused_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int S = mi_fp8_gemm_plan_splits(M, N, K);
+  return S > 0 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+}
+
+#define FUSED_PROLOGUE(NAME)                                                                              \
+  MI_CHECK_ARG(M >= 0 && N > 0 && K > 0);                                                                 \
+  if (M == 0) return MI_OK;                                                                               \
+  MI_CHECK_ARG(a && b_nk && scale_a && scale_b);                                                          \
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);                                                     \
+  const int S = mi_fp8_gemm_plan_splits(M, N, K);                                                         \
+  if (S <= 0) MI_FAIL(MI_ERR_UNSUPPORTED, NAME ": decode shapes only (M <= 128, K %% 128 == 0)");         \
+  const int64_t need = (int64_t)S * M * N * (int64_t)sizeof(float);                                       \
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))                                \
+    MI_FAIL(MI_ERR_INVALID, NAME ": workspace of mi_fp8_gemm_fused_workspace_bytes() = %lld bytes needed", (long long)need)
+
+extern "C" int mi_fp8_gemm_add_rmsnorm_fp8(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                           void* residual, const void* norm_weight, void* out, void* q_out,
+                                           const float* q_scale, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                           int64_t ldb, float eps, int dtype, void* workspace,
+                                           int64_t workspace_bytes, void* stream) {
+  FUSED_PROLOGUE("mi_fp8_gemm_add_rmsnorm_fp8");
+  MI_CHECK_ARG(norm_weight && (out || q_out) && (!q_out || q_scale));
+  if (N % 8 != 0 || N > 256 * 8 * 8) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_add_rmsnorm_fp8: N must be a multiple of 8, <= 16384");
+  const int rc = mi_fp8_gemm_partial(a, b_nk, (float*)workspace, M, N, K, lda, ldb, stream);
+  if (rc != MI_OK) return rc;
+  return slab_add_rmsnorm_fp8((const float*)workspace, S, scale_a, scale_b, residual, norm_weight, q_out, q_scale, out,
+                              M, N, eps, dtype, stream);
+}
+
+extern "C" int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                        const int64_t* positions, const float* cos_sin_cache, void* q_out,
+                                        void* k_cache, void* v_cache, const int64_t* loc, int64_t M,
+                                        int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t K,
+                                        int64_t lda, int64_t ldb, int64_t ldq, int64_t cache_stride_k,
+                                        int64_t cache_stride_v, int dtype, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  const int64_t N = (num_q_heads + 2 * num_kv_heads) * head_dim;
+  FUSED_PROLOGUE("mi_fp8_gemm_rope_kvwrite");
+  MI_CHECK_ARG(positions && cos_sin_cache && q_out && k_cache && v_cache && loc && num_q_heads > 0 && num_kv_heads > 0);
+  if (head_dim % 16 != 0 || ldq % 8 || cache_stride_k % 8 || cache_stride_v % 8)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_rope_kvwrite: head_dim %% 16 and 16-byte aligned rows required");
+  const int rc = mi_fp8_gemm_partial(a, b_nk, (float*)workspace, M, N, K, lda, ldb, stream);
+  if (rc != MI_OK) return rc;
+  return slab_rope_kvwrite((const float*)workspace, S, scale_a, scale_b, positions, cos_sin_cache, q_out, k_cache,
+                           v_cache, loc, M, num_q_heads, num_kv_heads, head_dim, ldq, cache_stride_k, cache_stride_v,
+                           dtype, stream);
+}
+
+extern "C" int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                        void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K,
+                                        int64_t lda, int64_t ldb, int dtype, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  MI_CHECK_ARG(I > 0 && q_out && q_scale);
+  if (M > 0 && a && b_nk && scale_a && scale_b) {   // in-kernel epilogue when the GEMM needs no split-K
+    const int rc = mi_fp8_gemm_silu_epilogue(a, b_nk, scale_a, scale_b, q_out, q_scale, M, I, K, lda, ldb, dtype, stream);
+    if (rc <= 0) return rc;
+  }
+  const int64_t N = 2 * I;
+  FUSED_PROLOGUE("mi_fp8_gemm_silu_mul_fp8");
+  if (I % 8 != 0) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_silu_mul_fp8: I must be a multiple of 8");
+  const int rc = mi_fp8_gemm_partial(a, b_nk, (float*)workspace, M, N, K, lda, ldb, stream);
+  if (rc != MI_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = M * (I / 8);
+  const unsigned blocks = (unsigned)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  if (dtype == MI_BF16)
+    slab_silu_mul_fp8_kernel<bf16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, scale_a, scale_b, (uint8_t*)q_out, q_scale, M, I);
+  else
+    slab_silu_mul_fp8_kernel<f16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, scale_a, scale_b, (uint8_t*)q_out, q_scale, M, I);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}

@@ -220,11 +220,64 @@ class LlamaStack:
         finally:
             Linear.calibrating = False
 
+    fuse_decode_layer = True   # linear + consumer fused forms on decode batches
+
+    def _fused_decode_ok(self, hidden, fb):
+        if not (LlamaStack.fuse_decode_layer and Linear.fuse_producer_quant) or Linear.calibrating:
+            return False
+        if not fb.forward_mode.is_decode() or hidden.shape[0] > 128:
+            return False
+        M = hidden.shape[0]
+        for L in self.layers:
+            for lin in (L.qkv, L.o, L.gate_up, L.down):
+                ok = getattr(lin.quant_method, "fused_decode_ok", None)
+                if ok is None or not ok(lin, M):
+                    return False
+        return True
+
+    def forward_decode_fused(self, hidden, positions, fb, backend):
+        """The same layer sequence as forward() with each FP8 linear fused with its consumer:
+        norm+quant | qkv+rope+kv-write | attention(+quant) | o+add+norm+quant | gate_up+silu*mul+quant |
+        down+add+norm(next layer)+quant  -- 7 launches per layer instead of 15, bit-identical results.
+        With TP>1 the row-parallel o/down outputs need the all-reduce first, so those two stay unfused."""
+        s, D = self.shape, self.shape.head_dim
+        pool = fb.token_to_kv_pool
+        residual = hidden
+        L0 = self.layers[0]
+        qx = ops.rmsnorm_fp8(hidden, L0.input_norm, s.rms_eps, L0.qkv.input_scale)
+        x = None
+        for i, L in enumerate(self.layers):
+            q = L.qkv.quant_method.apply_rope_kvwrite(L.qkv, qx, positions, self.cos_sin, pool.get_key_buffer(i),
+                                                      pool.get_value_buffer(i), fb.out_cache_loc, self.Hq, self.Hkv, D)
+            a8 = backend.forward(q, None, None, L.attn, fb, save_kv_cache=False, fp8_out_scale=L.o.input_scale)
+            if self.tp == 1:
+                _, qx = L.o.quant_method.apply_add_rmsnorm(L.o, a8, residual, L.post_norm, s.rms_eps,
+                                                           L.gate_up.input_scale)
+            else:
+                h = self._all_reduce(L.o.forward_prequantized(a8, self.dtype))
+                qx = ops.rmsnorm_fp8(h, L.post_norm, s.rms_eps, L.gate_up.input_scale, residual=residual)
+            act8 = L.gate_up.quant_method.apply_silu_mul(L.gate_up, qx, L.down.input_scale, self.dtype)
+            last = i + 1 == len(self.layers)
+            nw = self.final_norm if last else self.layers[i + 1].input_norm
+            ns = None if last else self.layers[i + 1].qkv.input_scale
+            if self.tp == 1:
+                x, qx = L.down.quant_method.apply_add_rmsnorm(L.down, act8, residual, nw, s.rms_eps, ns)
+            else:
+                h = self._all_reduce(L.down.forward_prequantized(act8, self.dtype))
+                if last:
+                    x = ops.rmsnorm(h, nw, s.rms_eps, residual=residual)
+                else:
+                    qx = ops.rmsnorm_fp8(h, nw, s.rms_eps, ns, residual=residual)
+        logits = torch.matmul(x, self.lm_head.t())
+        return tensor_model_parallel_all_gather(logits, self.tp, self.group)
+
     def forward(self, hidden, positions, fb, backend, last_token_logits=None):
         """hidden [T, H] -> logits [T, vocab]; follows llama.py:245-268 with the fused add+norm form.
         last_token_logits = extend_seq_lens: logits only for each request's last token, as
         LogitsProcessor does for extend batches (logits_processor.py:308-330)."""
         s = self.shape
+        if last_token_logits is None and self._fused_decode_ok(hidden, fb):
+            return self.forward_decode_fused(hidden, positions, fb, backend)
         residual = None
         for L in self.layers:
             first = residual is None

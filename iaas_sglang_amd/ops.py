@@ -317,3 +317,104 @@ def silu_and_mul_fp8(x: torch.Tensor, q_scale: torch.Tensor) -> torch.Tensor:
     check(lib.mi_silu_and_mul_fp8(_ptr(x), None, _ptr(q), _ptr(q_scale), M, I2 // 2, x.stride(0), 0, _dt(x),
                                   _stream()), "mi_silu_and_mul_fp8")
     return q
+
+
+# ------------------------------------------- decode-shaped FP8 linears fused with their consumer
+def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o_fp8: torch.Tensor,
+                            o_scale: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,
+                            sm_scale: float, logit_cap: float = 0.0, num_splits: int = 1,
+                            workspace: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """decode_attention whose output stage also quantises for the following static-scale FP8 linear:
+    o_fp8 [B, Hq*D] = quant(o, o_scale), bit-identical to decode_attention + fp8_quant_per_tensor(scale)."""
+    B, Hq, D = q.shape
+    Hkv = k_buf.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == D
+    assert k_buf.stride(2) == 1 and k_buf.stride(1) == D and v_buf.stride(2) == 1 and v_buf.stride(1) == D
+    assert k_buf.dtype == q.dtype and v_buf.dtype == q.dtype
+    assert o_fp8.dtype == FP8_DTYPE and o_fp8.is_contiguous() and o_fp8.numel() == B * Hq * D
+    assert o_scale.dtype == torch.float32 and o_scale.numel() == 1
+    if o is not None:
+        assert o.dtype == q.dtype and o.stride(2) == 1 and o.stride(1) == D
+    if num_splits > 1:
+        need = decode_workspace_numel(B, Hq, D, num_splits)
+        assert workspace is not None and workspace.dtype == torch.float32 and workspace.numel() >= need
+    check(lib.mi_decode_attn_fp8out(_ptr(q), _ptr(k_buf), _ptr(v_buf), _ptr(o), _ptr(o_fp8), _ptr(o_scale),
+                                    _ptr(kv_indptr_t), _ptr(kv_indices_t),
+                                    _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
+                                    o.stride(0) if o is not None else Hq * D, k_buf.stride(0), v_buf.stride(0),
+                                    float(sm_scale), float(logit_cap), int(num_splits), _dt(q), _stream()),
+          "mi_decode_attn_fp8out")
+    return o_fp8
+
+
+def _fused_ws(M: int, N: int, K: int, device):
+    nbytes = lib.mi_fp8_gemm_fused_workspace_bytes(M, N, K)
+    if nbytes <= 0:
+        raise MiHotpathError(f"fused FP8 linear: decode shapes only (M={M} <= 128, K={K} % 128 == 0)")
+    return _gemm_workspace(nbytes, device), nbytes
+
+
+def _check_fp8_operands(a, b_kn, scale_a, scale_b):
+    assert a.dtype == FP8_DTYPE and b_kn.dtype == FP8_DTYPE and a.shape[1] == b_kn.shape[0]
+    assert a.stride(1) == 1 and b_kn.stride(0) == 1, "b must be the [K,N] view of [N,K] row-major storage"
+    assert scale_a.dtype == torch.float32 and scale_a.numel() == 1
+    assert scale_b.dtype == torch.float32 and scale_b.numel() == 1
+
+
+def fp8_gemm_add_rmsnorm(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                         residual: Optional[torch.Tensor], norm_weight: torch.Tensor, eps: float,
+                         q_scale: Optional[torch.Tensor] = None, want_out: bool = False):
+    """y = rmsnorm(a.b * sa * sb (+ residual, updated in place)) * w; returns (out | None, fp8(y) | None)."""
+    _check_fp8_operands(a, b_kn, scale_a, scale_b)
+    M, K = a.shape
+    N = b_kn.shape[1]
+    dt = norm_weight.dtype
+    assert norm_weight.is_contiguous() and norm_weight.numel() == N
+    if residual is not None:
+        assert residual.dtype == dt and residual.shape == (M, N) and residual.is_contiguous()
+    out = torch.empty(M, N, dtype=dt, device=a.device) if (want_out or q_scale is None) else None
+    q = torch.empty(M, N, dtype=FP8_DTYPE, device=a.device) if q_scale is not None else None
+    ws, nbytes = _fused_ws(M, N, K, a.device)
+    check(lib.mi_fp8_gemm_add_rmsnorm_fp8(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(residual),
+                                          _ptr(norm_weight), _ptr(out), _ptr(q), _ptr(q_scale), M, N, K, a.stride(0),
+                                          b_kn.stride(1), float(eps), _DT[dt], _ptr(ws), nbytes, _stream()),
+          "mi_fp8_gemm_add_rmsnorm_fp8")
+    return out, q
+
+
+def fp8_gemm_rope_kvwrite(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                          positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                          v_cache: torch.Tensor, loc: torch.Tensor, num_q_heads: int, num_kv_heads: int,
+                          head_dim: int) -> torch.Tensor:
+    """qkv linear + NeoX RoPE + KV-pool write; returns q [M, Hq*D] in the pool dtype."""
+    _check_fp8_operands(a, b_kn, scale_a, scale_b)
+    M, K = a.shape
+    N = b_kn.shape[1]
+    assert N == (num_q_heads + 2 * num_kv_heads) * head_dim
+    assert positions.dtype == torch.int64 and loc.dtype == torch.int64 and positions.numel() == M and loc.numel() == M
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim and cos_sin_cache.is_contiguous()
+    assert k_cache.dtype == v_cache.dtype and k_cache[0].is_contiguous() and v_cache[0].is_contiguous()
+    assert k_cache[0].numel() == num_kv_heads * head_dim and v_cache[0].numel() == num_kv_heads * head_dim
+    q = torch.empty(M, num_q_heads * head_dim, dtype=k_cache.dtype, device=a.device)
+    ws, nbytes = _fused_ws(M, N, K, a.device)
+    check(lib.mi_fp8_gemm_rope_kvwrite(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(positions),
+                                       _ptr(cos_sin_cache), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(loc), M,
+                                       num_q_heads, num_kv_heads, head_dim, K, a.stride(0), b_kn.stride(1), q.stride(0),
+                                       k_cache.stride(0), v_cache.stride(0), _dt(k_cache), _ptr(ws), nbytes, _stream()),
+          "mi_fp8_gemm_rope_kvwrite")
+    return q
+
+
+def fp8_gemm_silu_mul(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                      q_scale: torch.Tensor, act_dtype: torch.dtype) -> torch.Tensor:
+    """gate_up linear + SiLU(gate)*up + static FP8 quant; returns fp8 [M, I]."""
+    _check_fp8_operands(a, b_kn, scale_a, scale_b)
+    M, K = a.shape
+    N = b_kn.shape[1]
+    assert N % 2 == 0 and q_scale.dtype == torch.float32 and q_scale.numel() == 1
+    q = torch.empty(M, N // 2, dtype=FP8_DTYPE, device=a.device)
+    ws, nbytes = _fused_ws(M, N, K, a.device)
+    check(lib.mi_fp8_gemm_silu_mul_fp8(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(q), _ptr(q_scale), M,
+                                       N // 2, K, a.stride(0), b_kn.stride(1), _DT[act_dtype], _ptr(ws), nbytes,
+                                       _stream()), "mi_fp8_gemm_silu_mul_fp8")
+    return q

@@ -113,6 +113,33 @@ class Fp8LinearMethod(LinearMethodBase):
         return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1),
                             out_dtype, bias)
 
+    # ---- decode-shaped fused forms: this linear + the op(s) that consume its output in
+    # a Llama decoder layer, one GEMM launch + one consumer launch, bit-identical to the unfused sequence.
+    # All take an fp8 activation already quantised with layer.input_scale (static scheme).
+    @staticmethod
+    def fused_decode_ok(layer: torch.nn.Module, M: int) -> bool:
+        s = getattr(layer, "input_scale", None)
+        K = layer.weight.shape[0]
+        return (s is not None and s.numel() == 1 and layer.weight_scale.numel() == 1 and 0 < M <= 128
+                and K % 128 == 0 and getattr(layer, "bias", None) is None)
+
+    def apply_add_rmsnorm(self, layer, qx, residual, norm_weight, eps, next_scale=None, want_out=False):
+        """(out | None, fp8 | None) = rmsnorm(linear(qx) + residual) * norm_weight [-> fp8 with next_scale]."""
+        return ops.fp8_gemm_add_rmsnorm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),
+                                        residual, norm_weight, eps, next_scale, want_out)
+
+    def apply_rope_kvwrite(self, layer, qx, positions, cos_sin_cache, k_cache, v_cache, loc, num_q_heads,
+                           num_kv_heads, head_dim):
+        """q = rope(linear(qx)[:, :q]); k (rope) and v rows go straight into the KV pool at `loc`."""
+        return ops.fp8_gemm_rope_kvwrite(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),
+                                         positions, cos_sin_cache, k_cache, v_cache, loc, num_q_heads, num_kv_heads,
+                                         head_dim)
+
+    def apply_silu_mul(self, layer, qx, next_scale, act_dtype):
+        """fp8(silu(gate) * up) of linear(qx) = [gate | up], quantised with next_scale."""
+        return ops.fp8_gemm_silu_mul(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),
+                                     next_scale, act_dtype)
+
     def __init__(self, quant_config: Fp8Config):
         self.quant_config = quant_config
 

@@ -86,6 +86,17 @@ int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
                    int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
                    int dtype, void* stream);
 
+/* mi_decode_attn with the static per-tensor FP8 quantisation of the FOLLOWING linear (o_proj) fused into the
+ * output stage: o_fp8 [B, Hq*D] contiguous = quant(o rounded to `dtype`, *o_scale), bit-identical to
+ * mi_decode_attn followed by mi_fp8_quant_per_tensor(mode 1).  `o` may be null (fp8 only).
+ * replaces: decode_attention_fwd + the scaled_fp8_quant in front of o_proj (fp8_utils.py:654-674). */
+int mi_decode_attn_fp8out(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                          void* o_fp8, const float* o_scale, const int32_t* kv_indptr,
+                          const int32_t* kv_indices, void* workspace, int64_t batch, int64_t num_q_heads,
+                          int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                          int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot,
+                          float sm_scale, float logit_cap, int64_t num_splits, int dtype, void* stream);
+
 /* Ragged extend (prefill-with-prefix) attention.
  *   q_ext [E,Hq,D], k_ext/v_ext [E,Hkv,D] : the new tokens, request i owns rows
  *   qo_indptr[i]..qo_indptr[i+1]; its cached prefix is kv_indices[kv_indptr[i]..kv_indptr[i+1])
@@ -234,6 +245,46 @@ int mi_rope_neox(void* q, void* k, const int64_t* positions, const float* cos_si
  * replaces: SiluAndMul.forward_native, layers/activation.py:56-58 (csrc/elementwise/activation.cu). */
 int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx, int64_t ldo,
                     int dtype, void* stream);
+
+/* ------------------------- decode-shaped FP8 linears fused with their consumer
+ *
+ * M <= 128, K % 128 == 0, per-tensor scales.  The GEMM leaves raw fp32 split-K partials in `workspace`
+ * (mi_fp8_gemm_fused_workspace_bytes(M,N,K) bytes, 16-byte aligned) and ONE consumer kernel sums them,
+ * applies the GEMM epilogue x = round_T(acc * sa * sb) and the next op(s) of the decoder layer.  Every
+ * rounding of the unfused call sequence is reproduced: results are bit-identical to it (tests/test_fused_gpu.py).
+ * Each call replaces 3-5 launches of the unfused sequence at decode batch sizes. */
+int64_t mi_fp8_gemm_fused_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* x = a.b (o_proj / down_proj);  x32 = x (+ residual, updated in place, nullable);
+ * y = rmsnorm(x32) * norm_weight -> out (T, nullable) and/or q_out = fp8(y / *q_scale) (nullable).
+ * replaces: apply_fp8_linear (fp8_utils.py:715-723) + RMSNorm.forward_native with residual
+ * (layernorm.py:128-146) + the static scaled_fp8_quant of the next linear (fp8_utils.py:654-658). */
+int mi_fp8_gemm_add_rmsnorm_fp8(const void* a, const void* b_nk, const float* scale_a,
+                                const float* scale_b, void* residual, const void* norm_weight,
+                                void* out, void* q_out, const float* q_scale, int64_t M, int64_t N,
+                                int64_t K, int64_t lda, int64_t ldb, float eps, int dtype,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* qkv = a.b_nk with N = (Hq + 2*Hkv)*D; NeoX RoPE on q and k; q -> q_out [M, Hq*D] (row stride ldq);
+ * k -> k_cache[loc[t]], v -> v_cache[loc[t]] (slot strides in elements).
+ * replaces: apply_fp8_linear + RotaryEmbedding.forward_native (rotary_embedding.py:49-166) +
+ * MHATokenToKVPool.set_kv_buffer (memory_pool.py:454-455). */
+int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const float* scale_a,
+                             const float* scale_b, const int64_t* positions,
+                             const float* cos_sin_cache, void* q_out, void* k_cache, void* v_cache,
+                             const int64_t* loc, int64_t M, int64_t num_q_heads, int64_t num_kv_heads,
+                             int64_t head_dim, int64_t K, int64_t lda, int64_t ldb, int64_t ldq,
+                             int64_t cache_stride_k, int64_t cache_stride_v, int dtype,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* gate_up = a.b_nk with N = 2*I; q_out [M, I] = fp8(round_T(silu(gate) * up) / *q_scale).  When the GEMM
+ * needs no split-K (N large enough to fill the chip) the activation runs in the GEMM's own epilogue and
+ * the [M, 2I] intermediate never exists; otherwise through the workspace as above.
+ * replaces: apply_fp8_linear + SiluAndMul.forward_native (activation.py:56-58) + static scaled_fp8_quant. */
+int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const float* scale_a,
+                             const float* scale_b, void* q_out, const float* q_scale, int64_t M,
+                             int64_t I, int64_t K, int64_t lda, int64_t ldb, int dtype,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,180 @@
+"""Fused decode-layer forms vs the unfused call sequence through the same C ABI:
+the fused entry points promise BIT-IDENTICAL results (every rounding of the unfused sequence is
+reproduced), so every comparison here is torch.equal.  The unfused pieces are themselves pinned to the
+oracle in test_quant_gpu.py / test_elementwise_gpu.py / test_attention_gpu.py / test_e2e_gpu.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+FP8 = torch.float8_e4m3fn
+
+
+def _fp8_operands(M, N, K, g, amp=1.0):
+    from iaas_sglang_amd import ops
+    x = (torch.randn(M, K, generator=g) * amp).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    xs = (x.float().abs().max() / 448.0).reshape(1)
+    qx, _ = ops.fp8_quant_per_tensor(x, xs)
+    qw, ws = ops.fp8_quant_per_tensor(w, weight_mode=True)
+    return qx, qw.t(), xs, ws
+
+
+def _bits(t):
+    return t.view(torch.uint8) if t.dtype == FP8 else t.view(torch.int16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 4096, 4096), (128, 4096, 14336), (37, 4096, 4096), (1, 256, 512), (16, 1024, 256)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_gemm_add_rmsnorm_fp8_bit_identical(M, N, K, dtype, with_residual):
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    qx, w, xs, ws = _fp8_operands(M, N, K, g)
+    res = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(DEV)
+    qscale = torch.tensor([0.02], device=DEV)
+    # unfused: GEMM -> (add) rmsnorm with fp8 output
+    y = ops.fp8_gemm(qx, w, xs, ws, dtype)
+    r1 = res.clone()
+    out1 = ops.rmsnorm(y, nw, 1e-5, residual=r1 if with_residual else None)
+    q1, _ = ops.fp8_quant_per_tensor(out1, qscale)
+    r2 = res.clone()
+    out2, q2 = ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, r2 if with_residual else None, nw, 1e-5, qscale, want_out=True)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out1), _bits(out2))
+    assert torch.equal(_bits(q1), _bits(q2))
+    assert torch.equal(_bits(r1), _bits(r2))
+    # fp8-only and out-only forms
+    _, q3 = ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, res.clone() if with_residual else None, nw, 1e-5, qscale)
+    out4, q4 = ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, res.clone() if with_residual else None, nw, 1e-5, None)
+    assert torch.equal(_bits(q1), _bits(q3)) and q4 is None and torch.equal(_bits(out1), _bits(out4))
+
+
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(128, 32, 8, 128, 4096), (5, 32, 8, 128, 4096), (64, 8, 2, 64, 256),
+                                          (17, 4, 4, 128, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_rope_kvwrite_bit_identical(M, Hq, Hkv, D, K, dtype):
+    from iaas_sglang_amd import harness as H, ops
+    g = torch.Generator().manual_seed(M + Hq + K)
+    N = (Hq + 2 * Hkv) * D
+    qx, w, xs, ws = _fp8_operands(M, N, K, g)
+    slots = 4 * M + 1
+    cache = H.rope_cache(D, 4096, 10000.0, DEV)
+    pos = torch.randint(0, 4096, (M,), generator=g).to(DEV)
+    loc = (torch.randperm(slots - 1, generator=g)[:M] + 1).to(DEV)
+    kc1 = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    vc1 = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    qkv = ops.fp8_gemm(qx, w, xs, ws, dtype)
+    q1, k1, v1 = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    ops.rope_neox_(q1, k1, pos, cache, D)
+    ops.kv_write(kc1, vc1, loc, k1, v1)
+    q2 = ops.fp8_gemm_rope_kvwrite(qx, w, xs, ws, pos, cache, kc2, vc2, loc, Hq, Hkv, D)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(q1.contiguous()), _bits(q2))
+    assert torch.equal(_bits(kc1), _bits(kc2)) and torch.equal(_bits(vc1), _bits(vc2))   # written rows AND untouched rows
+
+
+@pytest.mark.parametrize("M,I,K", [(128, 14336, 4096), (77, 14336, 4096), (128, 1792, 4096), (3, 512, 256), (16, 64, 128),
+                                   (128, 1000 * 8, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_silu_mul_fp8_bit_identical(M, I, K, dtype):
+    """Covers both routes: the in-kernel epilogue (N large, no split-K: 14336) and the slab consumer."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(M + I + K)
+    qx, w, xs, ws = _fp8_operands(M, 2 * I, K, g, amp=2.0)
+    qscale = torch.tensor([0.05], device=DEV)
+    gu = ops.fp8_gemm(qx, w, xs, ws, dtype)
+    q1 = ops.silu_and_mul_fp8(gu, qscale)
+    q2 = ops.fp8_gemm_silu_mul(qx, w, xs, ws, qscale, dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(q1), _bits(q2))
+    assert int((_bits(q1) != 0).sum()) > q1.numel() // 4      # not a trivially-zero comparison
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,splits", [(128, 32, 8, 128, 4), (7, 32, 8, 128, 1), (16, 8, 8, 64, 3), (5, 4, 1, 64, 1)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_decode_attention_fp8out_bit_identical(B, Hq, Hkv, D, splits, dtype):
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(B + Hq + D)
+    lens = torch.randint(1, 300, (B,), generator=g)
+    lens[0] = 1
+    total = int(lens.sum())
+    kb = torch.randn(total + 1, Hkv, D, generator=g).to(dtype).to(DEV)
+    vb = torch.randn(total + 1, Hkv, D, generator=g).to(dtype).to(DEV)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype).to(DEV)
+    indptr = ops.kv_indptr(lens.to(DEV))
+    idx = (torch.randperm(total, generator=g) + 1).to(torch.int32).to(DEV)
+    ws = torch.empty(max(ops.decode_workspace_numel(B, Hq, D, splits), 1), dtype=torch.float32, device=DEV)
+    scale = torch.tensor([0.01], device=DEV)
+    o1 = torch.empty_like(q)
+    ops.decode_attention(q, kb, vb, o1, indptr, idx, D ** -0.5, 0.0, splits, ws)
+    q1, _ = ops.fp8_quant_per_tensor(o1.view(B, Hq * D), scale)
+    o8 = torch.empty(B, Hq * D, dtype=FP8, device=DEV)
+    o2 = torch.empty_like(q)
+    ops.decode_attention_fp8out(q, kb, vb, o8, scale, indptr, idx, D ** -0.5, 0.0, splits, ws, o=o2)
+    o8b = torch.empty(B, Hq * D, dtype=FP8, device=DEV)
+    ops.decode_attention_fp8out(q, kb, vb, o8b, scale, indptr, idx, D ** -0.5, 0.0, splits, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(o1), _bits(o2))
+    assert torch.equal(_bits(q1), _bits(o8)) and torch.equal(_bits(q1), _bits(o8b))
+
+
+def _decode_logits(stack, runner, backend, fb, hidden, fused):
+    from iaas_sglang_amd import harness as H
+    H.LlamaStack.fuse_decode_layer = fused
+    try:
+        backend.init_forward_metadata(fb)
+        return stack.forward(hidden.clone(), fb.positions, fb, backend)
+    finally:
+        H.LlamaStack.fuse_decode_layer = True
+
+
+@pytest.mark.parametrize("batch,seq", [(128, 64), (9, 200)])
+def test_llama_layer_stack_fused_equals_unfused(batch, seq):
+    """Two Llama-3-8B-shaped layers, static FP8 scheme: logits and KV-pool contents of the fused decode step
+    are bit-identical to the unfused plugin-surface sequence (15 launches per layer vs 7)."""
+    import dataclasses
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import Fp8Config
+
+    shape = dataclasses.replace(H.LLAMA3_8B, layers=2, vocab=4096)
+    dtype = torch.bfloat16
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+    runner = H.make_runner(shape, max_reqs=batch, ctx=seq + 8, pool_tokens=batch * seq, dtype=dtype, device=DEV,
+                           fill_kv=True)
+    backend = MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, DEV, weight_range=0.02)
+    fb = H.make_decode_batch(runner, backend, batch, seq, DEV, seed=3)
+    g = torch.Generator().manual_seed(1)
+    hidden = torch.randn(batch, shape.hidden, generator=g).to(dtype).to(DEV)
+    backend.init_forward_metadata(fb)
+    stack.calibrate_static_input_scales(hidden.clone(), fb.positions, fb, backend)
+    pool = runner.token_to_kv_pool
+    snap = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    assert stack._fused_decode_ok(hidden, fb)
+    l_unfused = _decode_logits(stack, runner, backend, fb, hidden, fused=False)
+    kv_unfused = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    for b, s0 in zip(pool.k_buffer + pool.v_buffer, snap):
+        b.copy_(s0)
+    l_fused = _decode_logits(stack, runner, backend, fb, hidden, fused=True)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(l_unfused), _bits(l_fused))
+    for b, ref in zip(pool.k_buffer + pool.v_buffer, kv_unfused):
+        assert torch.equal(_bits(b), _bits(ref))
+    assert float(l_fused.float().abs().max()) > 0
+
+
+def test_fused_entry_points_reject_bad_arguments():
+    from iaas_sglang_amd import ops
+    from iaas_sglang_amd._lib import MiHotpathError
+    g = torch.Generator().manual_seed(0)
+    qx, w, xs, ws = _fp8_operands(200, 256, 256, g)          # M > 128: not a decode shape
+    with pytest.raises(MiHotpathError):
+        ops.fp8_gemm_silu_mul(qx, w, xs, ws, torch.tensor([0.05], device=DEV), torch.bfloat16)
+    qx, w, xs, ws = _fp8_operands(8, 256, 192, g)            # K % 128 != 0
+    with pytest.raises(MiHotpathError):
+        ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, None, torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-5)
