@@ -65,8 +65,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
+// At least 2 waves per SIMD (<= 256 VGPRs) whatever W is: two 4-wave workgroups or one 8-wave workgroup
+// are then co-resident per CU.  G = 16 (128 accumulator VGPRs) is the exception.
 template <typename T, int D, int G, int W, bool NT>
-__global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(G >= 16 ? 1 : 2)))
+void decode_attn_kernel(const DecodeParams p) {
   constexpr int KS = D / 32;       // MFMA k-steps over the head dim
   constexpr int LPT = D / 8;       // lanes per V token row (16 B per lane)
   constexpr int TPR = 16 / LPT;    // tokens per 16-lane row per V load (1: D=128, 2: D=64)
@@ -136,20 +139,25 @@ __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams 
     vec8 kf[KS];
     uint4 vv[NLOAD];
   };
-  auto load_idx = [&](int32_t t0, int32_t& ik, int32_t (&iv)[NLOAD]) {
-    ik = idx[min(t0 + col, end - 1)];
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) iv[i] = idx[min(t0 + vtok + TPR * i, end - 1)];
-  };
-  auto load_tile = [&](Tile& t, int32_t ik, const int32_t (&iv)[NLOAD]) {
+  // kv_indices: ONE coalesced load covers 64 tokens (= 4 tiles), lane l holds idx[64*blk + l]; the lanes of
+  // a tile pick theirs with ds_bpermute (LDS crossbar, no LDS memory).  Block b+2 is requested while block b
+  // computes, so waiting for an index block never drains K/V loads issued after it.  (vmcnt retires in
+  // order: the previous form loaded 5 index dwords per tile AFTER the tile ahead of it and had to drain
+  // that tile before the next could be requested -- one tile in flight per wave.)
+  auto load_idx_block = [&](int32_t blk) __attribute__((always_inline)) -> int32_t { return idx[min(start + blk * 64 + lane, end - 1)]; };
+  auto load_tile = [&](Tile& t, int32_t vblk, int j) __attribute__((always_inline)) {   // tile j (0..3) of the block whose indices are vblk
+    const int32_t ik = __shfl(vblk, 16 * j + col);
     const T* kp = kb + (int64_t)ik * p.stride_k_slot;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) t.kf[ks] = __builtin_bit_cast(vec8, ldg16<NT>(kp + ks * 32));
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) t.vv[i] = ldg16<NT>(vb + (int64_t)iv[i] * p.stride_v_slot);
+    for (int i = 0; i < NLOAD; ++i) {
+      const int32_t iv = __shfl(vblk, 16 * j + vtok + TPR * i);
+      t.vv[i] = ldg16<NT>(vb + (int64_t)iv * p.stride_v_slot);
+    }
   };
 
-  auto compute = [&](const Tile& t, int32_t t0) {
+  auto compute = [&](const Tile& t, int32_t t0) __attribute__((always_inline)) {
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) sacc = Elem<T>::mfma16(t.kf[ks], qf[ks], sacc);
@@ -213,25 +221,33 @@ __global__ __launch_bounds__(W * 64) void decode_attn_kernel(const DecodeParams 
     }
   };
 
-  // ---- main loop, 16 tokens per tile, next tile's K/V and the one after's indices in flight
-  Tile ta, tb;
-  int32_t ik, iv[NLOAD];
-  load_idx(start, ik, iv);
-  load_tile(ta, ik, iv);
-  if (start + 16 < end) load_idx(start + 16, ik, iv);
-  for (int32_t t0 = start; t0 < end; t0 += 32) {
-    const bool has_b = t0 + 16 < end;
-    if (has_b) {
-      load_tile(tb, ik, iv);
-      if (t0 + 32 < end) load_idx(t0 + 32, ik, iv);
-    }
-    compute(ta, t0);
-    if (!has_b) break;
-    if (t0 + 32 < end) {
-      load_tile(ta, ik, iv);
-      if (t0 + 48 < end) load_idx(t0 + 48, ik, iv);
-    }
-    compute(tb, t0 + 16);
+  // ---- main loop: a ring of NB tile buffers (16 tokens each).  Tile n+NB is requested right after tile n
+  // has been consumed, so NB-1 tiles (8 KB each at D=128) stay in flight per wave while one computes.
+  constexpr int NB = (G * 8 + (KS + NLOAD) * 4 * 4 <= 176) ? 4 : 2;   // acc + ring VGPRs; NB in {2,4} tiles a block
+  const int32_t ntiles = (end - start + 15) >> 4;
+  Tile tl[NB];
+  int32_t vcur = load_idx_block(0);
+  int32_t vnext = load_idx_block(1);
+  static_for<0, NB>([&](auto ji) {
+    constexpr int j = decltype(ji)::value;
+    if (j < ntiles) load_tile(tl[j], vcur, j);
+  });
+  for (int32_t tb = 0; tb < ntiles; tb += 4) {   // one 64-token index block per iteration
+    const int32_t vafter = load_idx_block((tb >> 2) + 2);
+    static_for<0, 4>([&](auto ji) {
+      constexpr int j = decltype(ji)::value;
+      constexpr int slot = j % NB;
+      const int32_t tn = tb + j;
+      if (tn < ntiles) {
+        compute(tl[slot], start + tn * 16);
+        if (tn + NB < ntiles) {
+          if constexpr (j + NB < 4) load_tile(tl[slot], vcur, j + NB);
+          else load_tile(tl[slot], vnext, j + NB - 4);
+        }
+      }
+    });
+    vcur = vnext;
+    vnext = vafter;
   }
 
   // ---- combine the partial sums held by the 4 lane rows (and the TPR token sub-rows)
@@ -350,7 +366,7 @@ static int env_int(const char* name, int dflt) {
 
 template <typename T, int D, int G, int W>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
-  static const int nt = env_int("MI_DECODE_NT", 0);
+  static const int nt = env_int("MI_DECODE_NT", 1);   // streamed-once KV rows: non-temporal (+3 % measured)
   dim3 grid((unsigned)p.num_splits, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)batch);
   if (nt) decode_attn_kernel<T, D, G, W, true><<<grid, W * 64, 0, st>>>(p);
   else decode_attn_kernel<T, D, G, W, false><<<grid, W * 64, 0, st>>>(p);
@@ -362,7 +378,7 @@ static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st
   const int h = p.num_kv_heads;
   if (wenv == 4 && h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
   else if (wenv == 2 && h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
-  else if (h % 8 == 0) launch_decode<T, D, G, 8>(p, batch, st);
+  else if (h % 8 == 0 && G < 16) launch_decode<T, D, G, 8>(p, batch, st);   // G=16: 128 accumulator VGPRs, keep the 512-VGPR budget of <= 4 waves
   else if (h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
   else if (h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
   else launch_decode<T, D, G, 1>(p, batch, st);

@@ -73,7 +73,9 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     monkeypatch.setattr(ab.ops, "cu_count", lambda: 256)
     be = ab.MiAttnBackend(_fake_runner())
     assert be.get_cuda_graph_seq_len_fill_value() == 1 and be.support_triton() is False
-    assert be._choose_splits(128, 128 * 2048) == 4          # 1024 (b, kv-head) waves -> 4 splits fill 256 CUs x 16
+    assert be._choose_splits(128, 128 * 2048) == 2          # 128 requests x 2 splits = 256 workgroups = one full round
+    assert be._choose_splits(64, 64 * 2048) == 4            # 64 x 4 = 256 workgroups
+    assert be._choose_splits(96, 96 * 2048) in (2, 5)       # 192 or 480 workgroups: never 3 (288 = 1.1 rounds)
     assert be._choose_splits(1, 100) == 1                    # never split below ~256 keys
     assert be._choose_splits(1, 100000) == 8                 # capped by --triton-attention-num-kv-splits
     assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
