@@ -261,133 +261,18 @@ static void launch_skinny(const GemmParams& p, hipStream_t st) {
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales; one `vmcnt(0)` + barrier per phase.
 // S == 1: scale/bias epilogue directly; S > 1: fp32 partial tile to slab[sp][M][N], summed by
 // fp8_gemm_reduce_kernel.
-// EPI = 1 (gate_up of a gated MLP, N = 2*I, S == 1, NWV == 8): waves 0-3 own four 16-row GATE tiles, waves
-// 4-7 the UP tiles of the same output columns; the epilogue exchanges the up values through LDS and writes
-// fp8(silu(gate) * up) [M, I] with the static scale *q_scale -- bit-identical to the bf16 GEMM output
-// followed by mi_silu_and_mul_fp8 (activation.py:56-58 + static quant), without the [M, 2I] round trip.
 struct SiluEpi {
   uint8_t* q_out;
   const float* q_scale;
 };
-template <typename OutT, int MT, int NWV, int NST, int EPI = 0>   // NST = LDS ring depth (2 or 3 stages)
-__global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
-                                                               int S, int phases_per_wg, int force_slab,
-                                                               const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
-  constexpr int PW = 256;                       // phase width (bytes of K) = 2 MFMA k-chunks
-  constexpr int ROWS = MT * 16;
-  constexpr int XBYTES = ROWS * PW;             // x block of one stage
-  constexpr int STAGE = XBYTES + NWV * 16 * PW; // + one 16-row weight block per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+// Epilogue of the decode-shaped kernel (a function so that kernel variants can share it): every wave is past
+// the last phase barrier when it is called, so LDS may be reused (EPI == 1 exchange buffer).
+template <typename OutT, int MT, int NWV, int EPI>
+__device__ __forceinline__ void xs_epilogue(const GemmParams& p, float* __restrict__ slab, int S, int sp, int force_slab,
+                                            const SiluEpi& epi, f32x4 (&acc)[MT], char* smem, int64_t n0, int64_t c0,
+                                            int64_t Ihalf, bool tile_ok, int lane, int wave) {
   const int r16 = lane & 15, q = lane >> 4;
-  const int64_t Ihalf = p.N / 2;                // EPI only
-  const int64_t c0 = ((int64_t)blockIdx.x * (NWV / 2) + (wave & (NWV / 2 - 1))) * 16;   // EPI: output column of the tile
-  const int64_t n0 = EPI ? (wave < NWV / 2 ? c0 : Ihalf + c0) : ((int64_t)blockIdx.x * NWV + wave) * 16;
-  const int sp = blockIdx.y;
-  const int64_t KC = p.K / 128;                 // K % 128 == 0 on this path
-  const int64_t NPH = (KC + 1) / 2;
-  const int64_t ph0 = (int64_t)sp * phases_per_wg;
-  const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
-  const bool tile_ok = EPI ? c0 < Ihalf : n0 < p.N;
-  const uint32_t lds_base = lds_addr_of(smem);
-
-  f32x4 acc[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // DMA geometry: one instruction = 4 rows x 256 B; lane L -> row (L >> 4), LDS slot (L & 15);
-  // the global source slot is (L & 15) ^ (row & 15)
-  const int drow = lane >> 4, dslot = lane & 15;
-  const uint8_t* wrow[4];                       // this wave's weight rows, 4 per DMA instruction
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wrow[i] = p.b + min(n0 + i * 4 + drow, p.N - 1) * p.ldb;
-
-#define XS_STAGE(ph_, st_)                                                                          \
-  {                                                                                                 \
-    const int64_t kb_ = (int64_t)(ph_) * PW;                                                        \
-    const int nslot_ = (int)min((int64_t)16, (p.K - kb_) / 16);                                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {             /* weights: rows 4i .. 4i+3 */      \
-      const int row_ = i * 4 + drow;                                                                \
-      int ss_ = dslot ^ (row_ & 15);                                                                \
-      ss_ = ss_ < nslot_ ? ss_ : 0;                                                                 \
-      glds16(wrow[i] + kb_ + ss_ * 16, lds_base + (st_) * STAGE + XBYTES + (wave * 16 + i * 4) * PW); \
-    }                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < (ROWS / 4 + NWV - 1) / NWV; ++i) {   /* x rows */         \
-      const int rr_ = (i * NWV + wave) * 4;                                                         \
-      if (rr_ < ROWS) {                                                                             \
-        const int row_ = rr_ + drow;                                                                \
-        int ss_ = dslot ^ (row_ & 15);                                                              \
-        ss_ = ss_ < nslot_ ? ss_ : 0;                                                               \
-        glds16(p.a + min((int64_t)row_, p.M - 1) * p.lda + kb_ + ss_ * 16, lds_base + (st_) * STAGE + rr_ * PW); \
-      }                                                                                             \
-    }                                                                                               \
-  }
-#define XS_MMA(ph_, st_)                                                                                   \
-  if (tile_ok) {                                                                                           \
-    const int nch_ = (int)min((int64_t)2, KC - (int64_t)(ph_) * 2);                                        \
-    const char* xb_ = smem + (st_) * STAGE + r16 * PW;                                                     \
-    const char* wb_ = smem + (st_) * STAGE + XBYTES + (wave * 16 + r16) * PW;                              \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                        \
-      if (c < nch_) {                                                                                      \
-        const int o0_ = ((c * 8 + q) ^ r16) * 16, o1_ = ((c * 8 + 4 + q) ^ r16) * 16;                      \
-        const uint4 w0_ = *(const uint4*)(wb_ + o0_), w1_ = *(const uint4*)(wb_ + o1_);                    \
-        const i32x8 wf_ = {(int)w0_.x, (int)w0_.y, (int)w0_.z, (int)w0_.w,                                 \
-                           (int)w1_.x, (int)w1_.y, (int)w1_.z, (int)w1_.w};                                \
-        _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                   \
-          const uint4 x0_ = *(const uint4*)(xb_ + t * 16 * PW + o0_);                                      \
-          const uint4 x1_ = *(const uint4*)(xb_ + t * 16 * PW + o1_);                                      \
-          const i32x8 xf_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w,                               \
-                             (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w};                              \
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf_, xf_, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
-        }                                                                                                  \
-      }                                                                                                    \
-    }                                                                                                      \
-  }
-  // NST stages in an LDS ring: NST-1 phases are in flight while one computes.  Each wave issues DPP DMA
-  // instructions per phase, so "phase ph+1 has landed, ph+2 may still fly" is a COUNTED wait vmcnt(DPP)
-  // (loads retire in order); the barrier then publishes every wave's pieces of phase ph+1.
-  constexpr int DPP = 4 + (ROWS / 4 + NWV - 1) / NWV;   // DMA instructions per wave per phase
-#define XS_BARRIER_AFTER(N_)                                      \
-  {                                                               \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");     \
-    __syncthreads();                                              \
-  }
-  if (ph0 < ph1) {
-    if constexpr (NST == 2) {
-      XS_STAGE(ph0, 0);
-      XS_BARRIER_AFTER(0);
-      for (int64_t ph = ph0; ph < ph1; ++ph) {
-        const int st = (int)((ph - ph0) & 1);
-        if (ph + 1 < ph1) XS_STAGE(ph + 1, st ^ 1);
-        XS_MMA(ph, st);
-        XS_BARRIER_AFTER(0);
-      }
-    } else {
-      XS_STAGE(ph0, 0);
-      if (ph0 + 1 < ph1) {
-        XS_STAGE(ph0 + 1, 1);
-        XS_BARRIER_AFTER(DPP);
-      } else {
-        XS_BARRIER_AFTER(0);
-      }
-      int st = 0;
-      for (int64_t ph = ph0; ph < ph1; ++ph) {
-        const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
-        if (ph + 2 < ph1) {
-          XS_STAGE(ph + 2, st2);
-          XS_MMA(ph, st);
-          XS_BARRIER_AFTER(DPP);                // phase ph+1 landed, ph+2 in flight
-        } else {
-          XS_MMA(ph, st);
-          XS_BARRIER_AFTER(0);
-        }
-        st = st == 2 ? 0 : st + 1;
-      }
-    }
-  }
-#undef XS_BARRIER_AFTER
-#undef XS_STAGE
-#undef XS_MMA
   if constexpr (EPI == 1) {
     // every wave is past the last phase barrier: the stages are free.  up waves publish round_T(acc*sa*sb+bias)
     f32x4* xch = (f32x4*)smem;                  // [NWV/2][MT][64] f32x4
@@ -478,6 +363,180 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
   }
 }
 
+// EPI = 1 (gate_up of a gated MLP, N = 2*I, S == 1, NWV == 8): waves 0-3 own four 16-row GATE tiles, waves
+// 4-7 the UP tiles of the same output columns; the epilogue exchanges the up values through LDS and writes
+// fp8(silu(gate) * up) [M, I] with the static scale *q_scale -- bit-identical to the bf16 GEMM output
+// followed by mi_silu_and_mul_fp8 (activation.py:56-58 + static quant), without the [M, 2I] round trip.
+template <typename OutT, int MT, int NWV, int NST, int EPI = 0>   // NST = LDS ring depth (2 or 3 stages)
+__global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams p, float* __restrict__ slab,
+                                                               int S, int phases_per_wg, int force_slab,
+                                                               const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
+  constexpr int PW = 256;                       // phase width (bytes of K) = 2 MFMA k-chunks
+  constexpr int ROWS = MT * 16;
+  constexpr int XBYTES = ROWS * PW;             // x block of one stage
+  constexpr int WBYTES = NWV * 16 * PW;         // one 16-row weight block per wave
+  constexpr int STAGE = XBYTES + WBYTES;
+  // NST == 5: SPLIT ring -- x in 2 stages [0, 2*XBYTES), weights in 3 wave-private stages behind them.  The
+  // weight block of phase ph+2 is requested two phases ahead and is the LAST thing each wave issues, so the
+  // per-phase wait is vmcnt(4) (x of ph+1 and weights of ph+1 landed, weights of ph+2 still flying): HBM
+  // latency is spread over two phases instead of one.  (All loads of a wave retire in order, so x -- needed
+  // one phase ahead -- must not be queued behind more than one weight block.)
+  constexpr bool SPLIT = (NST == 5);
+  auto x_off = [&](int st) { return SPLIT ? st * XBYTES : st * STAGE; };
+  auto w_off = [&](int st) { return SPLIT ? 2 * XBYTES + st * WBYTES : st * STAGE + XBYTES; };
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t Ihalf = p.N / 2;                // EPI only
+  const int64_t c0 = ((int64_t)blockIdx.x * (NWV / 2) + (wave & (NWV / 2 - 1))) * 16;   // EPI: output column of the tile
+  const int64_t n0 = EPI ? (wave < NWV / 2 ? c0 : Ihalf + c0) : ((int64_t)blockIdx.x * NWV + wave) * 16;
+  const int sp = blockIdx.y;
+  const int64_t KC = p.K / 128;                 // K % 128 == 0 on this path
+  const int64_t NPH = (KC + 1) / 2;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
+  const bool tile_ok = EPI ? c0 < Ihalf : n0 < p.N;
+  const uint32_t lds_base = lds_addr_of(smem);
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA geometry: one instruction = 4 rows x 256 B; lane L -> row (L >> 4), LDS slot (L & 15);
+  // the global source slot is (L & 15) ^ (row & 15)
+  const int drow = lane >> 4, dslot = lane & 15;
+  const uint8_t* wrow[4];                       // this wave's weight rows, 4 per DMA instruction
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wrow[i] = p.b + min(n0 + i * 4 + drow, p.N - 1) * p.ldb;
+
+#define XS_STAGE_W(ph_, st_)                                                                        \
+  {                                                                                                 \
+    const int64_t kb_ = (int64_t)(ph_) * PW;                                                        \
+    const int nslot_ = (int)min((int64_t)16, (p.K - kb_) / 16);                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {             /* weights: rows 4i .. 4i+3 */      \
+      const int row_ = i * 4 + drow;                                                                \
+      int ss_ = dslot ^ (row_ & 15);                                                                \
+      ss_ = ss_ < nslot_ ? ss_ : 0;                                                                 \
+      glds16(wrow[i] + kb_ + ss_ * 16, lds_base + w_off(st_) + (wave * 16 + i * 4) * PW);           \
+    }                                                                                               \
+  }
+#define XS_STAGE_X(ph_, st_)                                                                        \
+  {                                                                                                 \
+    const int64_t kb_ = (int64_t)(ph_) * PW;                                                        \
+    const int nslot_ = (int)min((int64_t)16, (p.K - kb_) / 16);                                     \
+    _Pragma("unroll") for (int i = 0; i < (ROWS / 4 + NWV - 1) / NWV; ++i) {   /* x rows */         \
+      const int rr_ = (i * NWV + wave) * 4;                                                         \
+      if (rr_ < ROWS) {                                                                             \
+        const int row_ = rr_ + drow;                                                                \
+        int ss_ = dslot ^ (row_ & 15);                                                              \
+        ss_ = ss_ < nslot_ ? ss_ : 0;                                                               \
+        glds16(p.a + min((int64_t)row_, p.M - 1) * p.lda + kb_ + ss_ * 16, lds_base + x_off(st_) + rr_ * PW); \
+      }                                                                                             \
+    }                                                                                               \
+  }
+#define XS_STAGE(ph_, st_)   \
+  {                          \
+    XS_STAGE_W(ph_, st_);    \
+    XS_STAGE_X(ph_, st_);    \
+  }
+#define XS_MMA(ph_, st_) XS_MMA2(ph_, st_, st_)
+#define XS_MMA2(ph_, xst_, wst_)                                                                           \
+  if (tile_ok) {                                                                                           \
+    const int nch_ = (int)min((int64_t)2, KC - (int64_t)(ph_) * 2);                                        \
+    const char* xb_ = smem + x_off(xst_) + r16 * PW;                                                       \
+    const char* wb_ = smem + w_off(wst_) + (wave * 16 + r16) * PW;                                         \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                        \
+      if (c < nch_) {                                                                                      \
+        const int o0_ = ((c * 8 + q) ^ r16) * 16, o1_ = ((c * 8 + 4 + q) ^ r16) * 16;                      \
+        const uint4 w0_ = *(const uint4*)(wb_ + o0_), w1_ = *(const uint4*)(wb_ + o1_);                    \
+        const i32x8 wf_ = {(int)w0_.x, (int)w0_.y, (int)w0_.z, (int)w0_.w,                                 \
+                           (int)w1_.x, (int)w1_.y, (int)w1_.z, (int)w1_.w};                                \
+        _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                   \
+          const uint4 x0_ = *(const uint4*)(xb_ + t * 16 * PW + o0_);                                      \
+          const uint4 x1_ = *(const uint4*)(xb_ + t * 16 * PW + o1_);                                      \
+          const i32x8 xf_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w,                               \
+                             (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w};                              \
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf_, xf_, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+  // NST stages in an LDS ring: NST-1 phases are in flight while one computes.  Each wave issues DPP DMA
+  // instructions per phase, so "phase ph+1 has landed, ph+2 may still fly" is a COUNTED wait vmcnt(DPP)
+  // (loads retire in order); the barrier then publishes every wave's pieces of phase ph+1.
+  constexpr int DPP = 4 + (ROWS / 4 + NWV - 1) / NWV;   // DMA instructions per wave per phase
+#define XS_BARRIER_AFTER(N_)                                      \
+  {                                                               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");     \
+    __syncthreads();                                              \
+  }
+  if (ph0 < ph1) {
+    if constexpr (SPLIT) {
+      XS_STAGE_X(ph0, 0);
+      XS_STAGE_W(ph0, 0);
+      if (ph0 + 1 < ph1) {
+        XS_STAGE_W(ph0 + 1, 1);
+        XS_BARRIER_AFTER(4);
+      } else {
+        XS_BARRIER_AFTER(0);
+      }
+      int ws = 0;
+      for (int64_t ph = ph0; ph < ph1; ++ph) {
+        const int xs = (int)((ph - ph0) & 1);
+        const int ws2 = ws == 0 ? 2 : ws - 1;   // (ws + 2) % 3
+        if (ph + 1 < ph1) XS_STAGE_X(ph + 1, xs ^ 1);
+        if (ph + 2 < ph1) {
+          XS_STAGE_W(ph + 2, ws2);
+          XS_MMA2(ph, xs, ws);
+          XS_BARRIER_AFTER(4);                  // x(ph+1), w(ph+1) landed; w(ph+2) in flight
+        } else {
+          XS_MMA2(ph, xs, ws);
+          XS_BARRIER_AFTER(0);
+        }
+        ws = ws == 2 ? 0 : ws + 1;
+      }
+    } else if constexpr (NST == 2) {
+      XS_STAGE(ph0, 0);
+      XS_BARRIER_AFTER(0);
+      for (int64_t ph = ph0; ph < ph1; ++ph) {
+        const int st = (int)((ph - ph0) & 1);
+        if (ph + 1 < ph1) XS_STAGE(ph + 1, st ^ 1);
+        XS_MMA(ph, st);
+        XS_BARRIER_AFTER(0);
+      }
+    } else {
+      XS_STAGE(ph0, 0);
+      if (ph0 + 1 < ph1) {
+        XS_STAGE(ph0 + 1, 1);
+        XS_BARRIER_AFTER(DPP);
+      } else {
+        XS_BARRIER_AFTER(0);
+      }
+      int st = 0;
+      for (int64_t ph = ph0; ph < ph1; ++ph) {
+        const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
+        if (ph + 2 < ph1) {
+          XS_STAGE(ph + 2, st2);
+          XS_MMA(ph, st);
+          XS_BARRIER_AFTER(DPP);                // phase ph+1 landed, ph+2 in flight
+        } else {
+          XS_MMA(ph, st);
+          XS_BARRIER_AFTER(0);
+        }
+        st = st == 2 ? 0 : st + 1;
+      }
+    }
+  }
+#undef XS_BARRIER_AFTER
+#undef XS_STAGE
+#undef XS_STAGE_W
+#undef XS_STAGE_X
+#undef XS_MMA
+#undef XS_MMA2
+  xs_epilogue<OutT, MT, NWV, EPI>(p, slab, S, sp, force_slab, epi, acc, smem, n0, c0, Ihalf, tile_ok, lane, wave);
+}
+
+
 // sum the S split-K slabs and apply the epilogue: one thread per 4 consecutive n
 template <typename OutT>
 __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p, const float* __restrict__ slab, int S) {
@@ -513,6 +572,10 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
   }
 }
 
+static int gemm_rotate() {
+  static const int r = [] { const char* e = getenv("MI_GEMM_ROTATE"); return e ? atoi(e) : 1; }();
+  return r;
+}
 static int xs_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -535,6 +598,9 @@ static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
   *S = (int)cdiv64(nph, per);
 }
 
+// LDS of the split ring (8 waves): 2 x stages + 3 weight stages = 160 KiB at M = 128 (all of a gfx950 CU's LDS)
+static size_t xs_split_lds(int mt) { return 2 * (size_t)mt * 16 * 256 + 3 * (size_t)8 * 16 * 256; }
+
 template <typename OutT, int MT>
 static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false) {
   const int nw = xs_waves(p.N);
@@ -542,7 +608,9 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
   dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
   const int fs = partial ? 1 : 0;
-  if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
+  static const int split = xs_env("MI_GEMM_XS_SPLIT", 1);
+  if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
+  else if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
   else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw, fs);
   else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw, fs);
   if (S > 1 && !partial) {
@@ -742,7 +810,7 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
   p.bias = bias; p.out = out; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.sa_row = scale_a_mode == MI_SCALE_ROW; p.sb_row = scale_b_mode == MI_SCALE_ROW;
   {
-    static const int rot_env = [] { const char* e = getenv("MI_GEMM_ROTATE"); return e ? atoi(e) : 1; }();
+    static const int rot_env = gemm_rotate();
     p.rotate = rot_env;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -770,7 +838,7 @@ MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slab
   MI_CHECK_ARG((((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)slabs) & 15) == 0);
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = nullptr; p.sb = nullptr; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = 0;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
   int S, ppw;
   xs_plan(N, K, &S, &ppw);
   hipStream_t st = (hipStream_t)stream;
@@ -796,12 +864,12 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   if (S != 1) return 1;
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = 0;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
 #define LAUNCH_EPI(TT, MTV)                                                                                    \
-  fp8_gemm_xs_kernel<TT, MTV, 8, 2, 1><<<grid, 512, 2 * (size_t)(MTV * 16 + 128) * 256, st>>>(p, nullptr, 1, ppw, 0, epi)
+  fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
   if (dtype == MI_BF16) {
     if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else LAUNCH_EPI(bf16_t, 8);
   } else {

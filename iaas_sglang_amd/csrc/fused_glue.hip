@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* 
   float v[VPT][8];
   float ss = 0.f;
   // slab sum in split order, then the GEMM epilogue exactly as fp8_gemm_reduce_kernel does it
-  // (acc * sa * sb, one rounding to T), then the residual add in fp32
+  // (acc * sa * sb, one rounding to T), then the residual add in fp32.  The kernel is latency-bound (one
+  // row per workgroup): all slab / residual loads of a thread are requested before the first add.
+  constexpr int SB = 8;   // slabs per batch of loads
+  const float sav = sa[0], sbv = sb[0];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int64_t c = threadIdx.x + i * 256;
@@ -57,17 +60,28 @@ __global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* 
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const f32x4 a = *(const f32x4*)(slab + (s * M + row) * H + c * 8);
-        const f32x4 b = *(const f32x4*)(slab + (s * M + row) * H + c * 8 + 4);
+      uint4 rres = make_uint4(0, 0, 0, 0);
+      if (residual) rres = *(const uint4*)(residual + row * H + c * 8);
+      for (int s0 = 0; s0 < S; s0 += SB) {
+        f32x4 a[SB], b[SB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        for (int s = 0; s < SB; ++s)
+          if (s0 + s < S) {
+            a[s] = *(const f32x4*)(slab + ((s0 + s) * M + row) * H + c * 8);
+            b[s] = *(const f32x4*)(slab + ((s0 + s) * M + row) * H + c * 8 + 4);
+          }
+#pragma unroll
+        for (int s = 0; s < SB; ++s)
+          if (s0 + s < S) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += a[s][j]; acc[4 + j] += b[s][j]; }
+          }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = rndT<T>(acc[j] * sa[0] * sb[0]);
+      for (int j = 0; j < 8; ++j) v[i][j] = rndT<T>(acc[j] * sav * sbv);
       if (residual) {
         float r[8];
-        unpack8g<T>(*(const uint4*)(residual + row * H + c * 8), r);
+        unpack8g<T>(rres, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] += r[j];
         *(uint4*)(residual + row * H + c * 8) = pack8g<T>(v[i]);
@@ -139,12 +153,22 @@ __global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __r
   float acc1[8], acc2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
-  for (int s = 0; s < S; ++s) {
-    const float* base = slab + (s * tokens + t) * N + col;
-    const f32x4 a = *(const f32x4*)base, b = *(const f32x4*)(base + 4);
-    const f32x4 e = *(const f32x4*)(base + half), f = *(const f32x4*)(base + half + 4);
+  constexpr int SB = 4;   // slabs per batch: all loads of a batch are requested before the first add
+  for (int s0 = 0; s0 < S; s0 += SB) {
+    f32x4 a[SB], b[SB], e[SB], f[SB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc1[j] += a[j]; acc1[4 + j] += b[j]; acc2[j] += e[j]; acc2[4 + j] += f[j]; }
+    for (int s = 0; s < SB; ++s)
+      if (s0 + s < S) {
+        const float* base = slab + ((s0 + s) * tokens + t) * N + col;
+        a[s] = *(const f32x4*)base; b[s] = *(const f32x4*)(base + 4);
+        e[s] = *(const f32x4*)(base + half); f[s] = *(const f32x4*)(base + half + 4);
+      }
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+      if (s0 + s < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[j] += a[s][j]; acc1[4 + j] += b[s][j]; acc2[j] += e[s][j]; acc2[4 + j] += f[s][j]; }
+      }
   }
   float x1[8], x2[8], o1[8], o2[8];
 #pragma unroll

@@ -25,7 +25,12 @@ __global__ __launch_bounds__(512) void rd(const uint4* __restrict__ buf, const i
         size_t off;   // in uint4 units; a row = 2 KiB = 128 uint4, wave w owns segment w (16 uint4)
         if (MODE == 0) off = ((size_t)blockIdx.x * rows_per_wg + r0 + u * 16 + i * 4 + (lane >> 4)) * 128 + wave * 16 + (lane & 15);
         else if (MODE == 1) off = (size_t)ri[r0 + u * 16 + i * 4 + (lane >> 4)] * 128 + wave * 16 + (lane & 15);
-        else off = (size_t)ri[r0 + u * 16 + (lane & 15)] * 128 + wave * 16 + i * 4 + (lane >> 4);
+        else if (MODE == 2) off = (size_t)ri[r0 + u * 16 + (lane & 15)] * 128 + wave * 16 + i * 4 + (lane >> 4);
+        else if (MODE == 3) off = ((size_t)((r0 + u * 16 + i * 4 + (lane >> 4)) & 255)) * 128 + wave * 16 + (lane & 15);   // every WG: the same 512 KiB, in lockstep
+        else {   // MODE 4: even instructions stream the WG's own chunk, odd ones read the shared 512 KiB
+          if (i & 1) off = ((size_t)((r0 + u * 16 + i * 4 + (lane >> 4)) & 255)) * 128 + wave * 16 + (lane & 15);
+          else off = ((size_t)blockIdx.x * rows_per_wg + r0 + u * 16 + i * 4 + (lane >> 4)) * 128 + wave * 16 + (lane & 15);
+        }
         v[u][i] = buf[off];
       }
 #pragma unroll
@@ -61,6 +66,18 @@ int main(int argc, char** argv) {
     printf("%-44s %8.1f us  %7.1f GB/s\n", name, us, rows * 2048.0 / us / 1e3);
   };
 #define RUN(U, M, label) run(label, [&](uint4* b) { rd<U, M><<<wgs, 512>>>(b, d_perm, rpw, d_out); })
+  // one 8-wave workgroup per CU (128 KiB of LDS each): does the bandwidth follow the bytes a CU keeps in flight?
+  auto run1 = [&](const char* name, auto kern) { run(name, kern); };
+#define RUN1(U, label) run1(label, [&](uint4* b) { rd<U, 0><<<256, 512, 131072>>>(b, d_perm, (int)(rows / 256), d_out); })
+  RUN1(1, "1 WG/CU (8 waves), 4 KiB/wave in flight");
+  RUN1(2, "1 WG/CU (8 waves), 8 KiB/wave in flight");
+  RUN1(4, "1 WG/CU (8 waves), 16 KiB/wave in flight");
+  RUN1(8, "1 WG/CU (8 waves), 32 KiB/wave in flight");
+#define RUN3(U, M, label) run1(label, [&](uint4* b) { rd<U, M><<<256, 512, 131072>>>(b, d_perm, (int)(rows / 256), d_out); })
+  RUN3(2, 3, "1 WG/CU, all WGs re-read one 512 KiB (L2)");
+  RUN3(4, 3, "1 WG/CU, all WGs re-read one 512 KiB (L2), 16K/wave");
+  RUN3(2, 4, "1 WG/CU, half stream / half shared 512 KiB");
+  RUN3(4, 4, "1 WG/CU, half stream / half shared, 16K/wave");
   RUN(1, 0, "contiguous, 4 KiB/wave in flight");
   RUN(2, 0, "contiguous, 8 KiB/wave in flight");
   RUN(4, 0, "contiguous, 16 KiB/wave in flight");
