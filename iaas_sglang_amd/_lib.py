@@ -25,11 +25,14 @@ SIGNATURES = {
     "mi_kv_indptr": (_int, [_p, _int, _p, _i64, _p]),
     "mi_kv_indices": (_int, [_p, _i64, _p, _p, _int, _p, _p, _p, _i64, _p]),
     "mi_kv_write": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "mi_kv_write_fp8": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _int, _p]),
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _f, _f, _i64, _int, _p]),
     "mi_decode_attn_fp8out": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                      _f, _f, _i64, _int, _p]),
+    "mi_decode_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,
+                                    _i64, _i64, _f, _f, _i64, _int, _p]),
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_merge_state": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),

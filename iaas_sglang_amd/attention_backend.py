@@ -151,10 +151,22 @@ class MiAttnBackend(AttentionBackend):
         pool = forward_batch.token_to_kv_pool
         return pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id)
 
+    @staticmethod
+    def _kv_scales(layer):
+        """(k_scale, v_scale) floats of an fp8 KV cache layer (radix_attention.py:71-74, loaded by
+        quantization/kv_cache.py:17-82); 1.0 when the checkpoint has none (plain cast, as Triton stores it)."""
+        ks = getattr(layer, "k_scale_float", None)
+        vs = getattr(layer, "v_scale_float", None)
+        return (1.0 if ks is None else float(ks)), (1.0 if vs is None else float(vs))
+
     def _save_kv(self, forward_batch, layer, k, v):
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
+        if k_buf.element_size() == 1:            # fp8 pool: divide by the scales and cast, one scatter kernel
+            ks, vs = self._kv_scales(layer)
+            ops.kv_write_fp8(k_buf, v_buf, forward_batch.out_cache_loc, k, v, ks, vs)
+            return
         if k.dtype != k_buf.dtype:
-            raise NotImplementedError("MiAttnBackend: fp8 KV cache (k_scale/v_scale) is a later row (SURVEY 8f-1)")
+            raise NotImplementedError(f"MiAttnBackend: KV pool dtype {k_buf.dtype} with {k.dtype} activations")
         ops.kv_write(k_buf, v_buf, forward_batch.out_cache_loc, k, v)
 
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True, fp8_out_scale=None):
@@ -168,6 +180,19 @@ class MiAttnBackend(AttentionBackend):
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
+        if k_buf.element_size() == 1:            # fp8 KV cache
+            ks, vs = self._kv_scales(layer)
+            q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            cap = getattr(layer, "logit_cap", 0.0) or 0.0
+            if fp8_out_scale is not None:
+                o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
+                ops.decode_attention_fp8kv(q3, k_buf, v_buf, md.kv_indptr, md.kv_indices, layer.scaling, ks, vs, cap,
+                                           md.num_kv_splits, md.workspace, o_fp8=o8, o_scale=fp8_out_scale)
+                return o8
+            o = q.new_empty(q.shape)
+            ops.decode_attention_fp8kv(q3, k_buf, v_buf, md.kv_indptr, md.kv_indices, layer.scaling, ks, vs, cap,
+                                       md.num_kv_splits, md.workspace, o=o.view(-1, layer.tp_q_head_num, layer.v_head_dim))
+            return o
         if fp8_out_scale is not None:
             o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
             ops.decode_attention_fp8out(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf, o8,
@@ -188,6 +213,16 @@ class MiAttnBackend(AttentionBackend):
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
+        if k_buf.element_size() == 1:
+            # fp8 pool: the new tokens are attended from the k/v ARGUMENTS (and were just written to the pool in
+            # fp8); only a cached prefix would be read back from the pool, and the extend kernel has no fp8
+            # staging path yet -> prefill without prefix works, prefix reuse does not
+            pre = forward_batch.extend_prefix_lens_cpu
+            if pre is None or sum(int(x) for x in pre) > 0:
+                raise NotImplementedError("MiAttnBackend: extend over a cached PREFIX in an fp8 KV pool is not wired "
+                                          "(prefill without prefix and decode are)")
+            k_buf = k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim)     # never dereferenced: no prefix keys
+            v_buf = v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim)
         causal = not (getattr(layer, "is_cross_attention", False)
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
         window = getattr(layer, "sliding_window_size", -1)

@@ -17,6 +17,7 @@
 // HBM-bound: algorithmic bytes = 2 * tokens * Hkv * D * sizeof(T) (+ indices, q, o).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct DecodeParams {
   const void* q;
@@ -31,6 +32,7 @@ struct DecodeParams {
   int64_t stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot;
   float scale_log2;  // sm_scale * log2(e)   (logit_cap == 0)
   float sm_scale, logit_cap;
+  float v_scale;         // fp8 KV: output multiplier (k_scale is folded into sm_scale / scale_log2 by the host)
   uint8_t* o_q;          // optional fp8 copy of o, [B][Hq*D] contiguous, = quant(T-rounded o, *o_qscale)
   const float* o_qscale;
 };
@@ -48,6 +50,28 @@ template <typename T> __device__ __forceinline__ uint32_t quant4_static(float a,
 
 // 16-byte global load; NT = non-temporal (streamed-once KV rows should not displace q / indices / partials)
 typedef __attribute__((ext_vector_type(4))) uint32_t ldg_u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t ldg_u32x2;
+template <bool NT> __device__ __forceinline__ uint2 ldg8(const void* p) {
+  if constexpr (NT) {
+    const ldg_u32x2 v = __builtin_nontemporal_load((const ldg_u32x2*)p);
+    return make_uint2(v[0], v[1]);
+  } else {
+    return *(const uint2*)p;
+  }
+}
+// 8 fp8 (e4m3fn) bytes -> 8 floats / one 8-element MFMA fragment of T (exact: every e4m3 value is a bf16 / fp16 value)
+typedef __attribute__((ext_vector_type(2))) float cvt_f32x2;
+__device__ __forceinline__ void fp8x8_to_f32(uint32_t lo, uint32_t hi, float (&f)[8]) {
+  const cvt_f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+  const cvt_f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+  f[0] = a[0]; f[1] = a[1]; f[2] = b[0]; f[3] = b[1]; f[4] = c[0]; f[5] = c[1]; f[6] = d[0]; f[7] = d[1];
+}
+template <typename T> __device__ __forceinline__ typename Elem<T>::vec8 fp8x8_to_frag(uint32_t lo, uint32_t hi) {
+  float f[8];
+  fp8x8_to_f32(lo, hi, f);
+  const uint4 u = make_uint4(pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3]), pack2<T>(f[4], f[5]), pack2<T>(f[6], f[7]));
+  return __builtin_bit_cast(typename Elem<T>::vec8, u);
+}
 template <bool NT> __device__ __forceinline__ uint4 ldg16(const void* p) {
   if constexpr (NT) {
     const ldg_u32x4 v = __builtin_nontemporal_load((const ldg_u32x4*)p);
@@ -67,11 +91,17 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 
 // At least 2 waves per SIMD (<= 256 VGPRs) whatever W is: two 4-wave workgroups or one 8-wave workgroup
 // are then co-resident per CU.  G = 16 (128 accumulator VGPRs) is the exception.
-template <typename T, int D, int G, int W, bool NT>
+// KV8: the pool holds fp8 e4m3fn (1 byte per element, strides in bytes).  K rows are fetched as 32 contiguous
+// bytes per lane (lane row r: dims 32r .. 32r+31, two 16-byte loads) and converted to T fragments; MFMA step j
+// then contracts dims 32r + 8j .. +8, so Q uses the same permuted dim order (any order gives the same sum).
+// V rows are fetched 8 bytes per lane (16 lanes = one 128-byte head row) and converted straight to fp32.
+template <typename T, int D, int G, int W, bool KV8>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(G >= 16 ? 1 : 2)))
 void decode_attn_kernel(const DecodeParams p) {
+  constexpr bool NT = true;        // streamed-once KV rows: non-temporal loads (+3 % measured)
+  static_assert(!KV8 || D == 128, "fp8 KV: head_dim 128 only");
   constexpr int KS = D / 32;       // MFMA k-steps over the head dim
-  constexpr int LPT = D / 8;       // lanes per V token row (16 B per lane)
+  constexpr int LPT = D / 8;       // lanes per V token row (8 elements per lane)
   constexpr int TPR = 16 / LPT;    // tokens per 16-lane row per V load (1: D=128, 2: D=64)
   constexpr int NLOAD = 4 / TPR;   // V loads per 16-token tile
   typedef typename Elem<T>::vec8 vec8;
@@ -114,18 +144,19 @@ void decode_attn_kernel(const DecodeParams p) {
   // ---- Q fragments (B operand): lane -> qhead col, dims 32*ks + 8*row .. +8
   vec8 qf[KS];
   {
-    const T* q = (const T*)p.q + (int64_t)b * p.stride_q_tok + (int64_t)(hq0 + col) * D + row * 8;
+    const T* q = (const T*)p.q + (int64_t)b * p.stride_q_tok + (int64_t)(hq0 + col) * D + (KV8 ? row * 32 : row * 8);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 z = make_uint4(0, 0, 0, 0);
-      if (col < group) z = *(const uint4*)(q + ks * 32);
+      if (col < group) z = *(const uint4*)(q + (KV8 ? ks * 8 : ks * 32));
       qf[ks] = __builtin_bit_cast(vec8, z);
     }
   }
 
   const int32_t* idx = p.kv_indices + base;
-  const T* kb = (const T*)p.k_buf + (int64_t)hk * D + row * 8;
-  const T* vb = (const T*)p.v_buf + (int64_t)hk * D + (col % LPT) * 8;
+  typedef typename std::conditional<KV8, uint8_t, T>::type TKV;
+  const TKV* kb = (const TKV*)p.k_buf + (int64_t)hk * D + (KV8 ? row * 32 : row * 8);
+  const TKV* vb = (const TKV*)p.v_buf + (int64_t)hk * D + (col % LPT) * 8;
   const int vtok = 4 * row + (col / LPT);  // + TPR * i
 
   float acc[G][8];
@@ -136,8 +167,8 @@ void decode_attn_kernel(const DecodeParams p) {
   float m = -INFINITY, lsum = 0.f;
 
   struct Tile {
-    vec8 kf[KS];
-    uint4 vv[NLOAD];
+    uint4 kf[KV8 ? 2 : KS];     // KV8: 32 raw bytes; else KS fragments of 8 T
+    uint4 vv[NLOAD];            // KV8: only .x/.y (8 bytes) are used
   };
   // kv_indices: ONE coalesced load covers 64 tokens (= 4 tiles), lane l holds idx[64*blk + l]; the lanes of
   // a tile pick theirs with ds_bpermute (LDS crossbar, no LDS memory).  Block b+2 is requested while block b
@@ -147,20 +178,37 @@ void decode_attn_kernel(const DecodeParams p) {
   auto load_idx_block = [&](int32_t blk) __attribute__((always_inline)) -> int32_t { return idx[min(start + blk * 64 + lane, end - 1)]; };
   auto load_tile = [&](Tile& t, int32_t vblk, int j) __attribute__((always_inline)) {   // tile j (0..3) of the block whose indices are vblk
     const int32_t ik = __shfl(vblk, 16 * j + col);
-    const T* kp = kb + (int64_t)ik * p.stride_k_slot;
+    const TKV* kp = kb + (int64_t)ik * p.stride_k_slot;
+    if constexpr (KV8) {
+      t.kf[0] = ldg16<NT>(kp);
+      t.kf[1] = ldg16<NT>(kp + 16);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) t.kf[ks] = __builtin_bit_cast(vec8, ldg16<NT>(kp + ks * 32));
+      for (int ks = 0; ks < KS; ++ks) t.kf[ks] = ldg16<NT>(kp + ks * 32);
+    }
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int32_t iv = __shfl(vblk, 16 * j + vtok + TPR * i);
-      t.vv[i] = ldg16<NT>(vb + (int64_t)iv * p.stride_v_slot);
+      if constexpr (KV8) {
+        const uint2 u = ldg8<NT>(vb + (int64_t)iv * p.stride_v_slot);
+        t.vv[i] = make_uint4(u.x, u.y, 0, 0);
+      } else {
+        t.vv[i] = ldg16<NT>(vb + (int64_t)iv * p.stride_v_slot);
+      }
     }
   };
 
   auto compute = [&](const Tile& t, int32_t t0) __attribute__((always_inline)) {
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KV8) {
+      sacc = Elem<T>::mfma16(fp8x8_to_frag<T>(t.kf[0].x, t.kf[0].y), qf[0], sacc);
+      sacc = Elem<T>::mfma16(fp8x8_to_frag<T>(t.kf[0].z, t.kf[0].w), qf[1], sacc);
+      sacc = Elem<T>::mfma16(fp8x8_to_frag<T>(t.kf[1].x, t.kf[1].y), qf[2], sacc);
+      sacc = Elem<T>::mfma16(fp8x8_to_frag<T>(t.kf[1].z, t.kf[1].w), qf[3], sacc);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sacc = Elem<T>::mfma16(t.kf[ks], qf[ks], sacc);
+      for (int ks = 0; ks < KS; ++ks) sacc = Elem<T>::mfma16(__builtin_bit_cast(vec8, t.kf[ks]), qf[ks], sacc);
+    }
     float sc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -199,11 +247,15 @@ void decode_attn_kernel(const DecodeParams p) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       float vf[8];
-      const uint32_t w[4] = {t.vv[i].x, t.vv[i].y, t.vv[i].z, t.vv[i].w};
+      if constexpr (KV8) {
+        fp8x8_to_f32(t.vv[i].x, t.vv[i].y, vf);
+      } else {
+        const uint32_t w[4] = {t.vv[i].x, t.vv[i].y, t.vv[i].z, t.vv[i].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        vf[2 * j] = Elem<T>::lo(w[j]);
-        vf[2 * j + 1] = Elem<T>::hi(w[j]);
+        for (int j = 0; j < 4; ++j) {
+          vf[2 * j] = Elem<T>::lo(w[j]);
+          vf[2 * j + 1] = Elem<T>::hi(w[j]);
+        }
       }
       static_for<0, G>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
@@ -223,7 +275,8 @@ void decode_attn_kernel(const DecodeParams p) {
 
   // ---- main loop: a ring of NB tile buffers (16 tokens each).  Tile n+NB is requested right after tile n
   // has been consumed, so NB-1 tiles (8 KB each at D=128) stay in flight per wave while one computes.
-  constexpr int NB = (G * 8 + (KS + NLOAD) * 4 * 4 <= 176) ? 4 : 2;   // acc + ring VGPRs; NB in {2,4} tiles a block
+  constexpr int TILE_VGPRS = KV8 ? (2 + NLOAD) * 4 : (KS + NLOAD) * 4;
+  constexpr int NB = (G * 8 + TILE_VGPRS * 4 <= 176) ? 4 : 2;   // acc + ring VGPRs; NB in {2,4} tiles a block
   const int32_t ntiles = (end - start + 15) >> 4;
   Tile tl[NB];
   int32_t vcur = load_idx_block(0);
@@ -271,7 +324,7 @@ void decode_attn_kernel(const DecodeParams p) {
     if (g < group && row == 0 && col < LPT) {
       const int64_t hq = hq0 + g;
       if (nsplit == 1) {
-        const float inv = 1.f / lg;
+        const float inv = KV8 ? p.v_scale / lg : 1.f / lg;
         uint4 out;
         out.x = pack2<T>(acc[g][0] * inv, acc[g][1] * inv);
         out.y = pack2<T>(acc[g][2] * inv, acc[g][3] * inv);
@@ -306,7 +359,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
                                                            const float* __restrict__ ws_ml, T* o,
                                                            int64_t n_bh, int32_t num_q_heads,
                                                            int32_t nsplit, int64_t stride_o_tok,
-                                                           uint8_t* __restrict__ o_q, const float* __restrict__ o_qscale) {
+                                                           uint8_t* __restrict__ o_q, const float* __restrict__ o_qscale,
+                                                           float out_scale) {
   constexpr int EPL = D / 64 > 0 ? D / 64 : 1;  // elements per lane
   const int lane = threadIdx.x & 63;
   const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -331,7 +385,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   }
   if (active) {
     const int64_t b = bh / num_q_heads, h = bh % num_q_heads;
-    const float inv = 1.f / L;
+    const float inv = out_scale == 1.f ? 1.f / L : out_scale / L;
     if (o) {
       T* out = o + b * stride_o_tok + h * D + lane * EPL;
 #pragma unroll
@@ -364,34 +418,32 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int D, int G, int W>
+template <typename T, int D, int G, int W, bool KV8>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
-  static const int nt = env_int("MI_DECODE_NT", 1);   // streamed-once KV rows: non-temporal (+3 % measured)
   dim3 grid((unsigned)p.num_splits, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)batch);
-  if (nt) decode_attn_kernel<T, D, G, W, true><<<grid, W * 64, 0, st>>>(p);
-  else decode_attn_kernel<T, D, G, W, false><<<grid, W * 64, 0, st>>>(p);
+  decode_attn_kernel<T, D, G, W, KV8><<<grid, W * 64, 0, st>>>(p);
 }
 
-template <typename T, int D, int G>
+template <typename T, int D, int G, bool KV8>
 static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st) {
   static const int wenv = env_int("MI_DECODE_W", 0);
   const int h = p.num_kv_heads;
-  if (wenv == 4 && h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
-  else if (wenv == 2 && h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
-  else if (h % 8 == 0 && G < 16) launch_decode<T, D, G, 8>(p, batch, st);   // G=16: 128 accumulator VGPRs, keep the 512-VGPR budget of <= 4 waves
-  else if (h % 4 == 0) launch_decode<T, D, G, 4>(p, batch, st);
-  else if (h % 2 == 0) launch_decode<T, D, G, 2>(p, batch, st);
-  else launch_decode<T, D, G, 1>(p, batch, st);
+  if (wenv == 4 && h % 4 == 0) launch_decode<T, D, G, 4, KV8>(p, batch, st);
+  else if (wenv == 2 && h % 2 == 0) launch_decode<T, D, G, 2, KV8>(p, batch, st);
+  else if (h % 8 == 0 && G < 16) launch_decode<T, D, G, 8, KV8>(p, batch, st);   // G=16: 128 accumulator VGPRs, keep the 512-VGPR budget of <= 4 waves
+  else if (h % 4 == 0) launch_decode<T, D, G, 4, KV8>(p, batch, st);
+  else if (h % 2 == 0) launch_decode<T, D, G, 2, KV8>(p, batch, st);
+  else launch_decode<T, D, G, 1, KV8>(p, batch, st);
 }
 
-template <typename T, int D>
+template <typename T, int D, bool KV8 = false>
 static int launch_decode_g(const DecodeParams& p, int64_t batch, hipStream_t st) {
   const int g = p.group;
-  if (g == 1) launch_decode_w<T, D, 1>(p, batch, st);
-  else if (g == 2) launch_decode_w<T, D, 2>(p, batch, st);
-  else if (g <= 4) launch_decode_w<T, D, 4>(p, batch, st);
-  else if (g <= 8) launch_decode_w<T, D, 8>(p, batch, st);
-  else if (g <= 16) launch_decode_w<T, D, 16>(p, batch, st);
+  if (g == 1) launch_decode_w<T, D, 1, KV8>(p, batch, st);
+  else if (g == 2) launch_decode_w<T, D, 2, KV8>(p, batch, st);
+  else if (g <= 4) launch_decode_w<T, D, 4, KV8>(p, batch, st);
+  else if (g <= 8) launch_decode_w<T, D, 8, KV8>(p, batch, st);
+  else if (g <= 16) launch_decode_w<T, D, 16, KV8>(p, batch, st);
   else return MI_ERR_UNSUPPORTED;
   return MI_OK;
 }
@@ -402,7 +454,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
                             int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                             int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
                             float logit_cap, int64_t num_splits, int dtype, void* stream, void* o_fp8,
-                            const float* o_scale) {
+                            const float* o_scale, bool kv8 = false, float k_scale = 1.f, float v_scale = 1.f) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
   MI_CHECK_ARG(q && k_buf && v_buf && (o || o_fp8) && kv_indptr && kv_indices);
@@ -413,6 +465,9 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (head_dim != 64 && head_dim != 128)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_decode_attn: head_dim %lld not supported (64, 128)", (long long)head_dim);
+  if (kv8 && head_dim != 128) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_decode_attn_fp8kv: head_dim 128 only");
+  MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
+  MI_CHECK_ARG(!kv8 || (stride_k_slot % 16 == 0 && stride_v_slot % 16 == 0));
   // 16-byte vector accesses on q/k/v/o rows
   MI_CHECK_ARG(stride_q_tok % 8 == 0 && stride_o_tok % 8 == 0 && stride_k_slot % 8 == 0 &&
                stride_v_slot % 8 == 0);
@@ -428,13 +483,17 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   p.group = (int32_t)(num_q_heads / num_kv_heads); p.num_splits = (int32_t)num_splits;
   p.stride_q_tok = stride_q_tok; p.stride_o_tok = stride_o_tok;
   p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
-  p.sm_scale = sm_scale; p.logit_cap = logit_cap;
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  // fp8 KV: logits = sm_scale * k_scale * (q . k8), out = v_scale * softmax . v8
+  p.sm_scale = kv8 ? sm_scale * k_scale : sm_scale; p.logit_cap = logit_cap;
+  p.scale_log2 = p.sm_scale * 1.4426950408889634f;
+  p.v_scale = kv8 ? v_scale : 1.f;
   p.o_q = (uint8_t*)o_fp8; p.o_qscale = o_scale;
   hipStream_t st = (hipStream_t)stream;
 
   int rc;
-  if (dtype == MI_BF16)
+  if (kv8)
+    rc = dtype == MI_BF16 ? launch_decode_g<bf16_t, 128, true>(p, batch, st) : launch_decode_g<f16_t, 128, true>(p, batch, st);
+  else if (dtype == MI_BF16)
     rc = head_dim == 128 ? launch_decode_g<bf16_t, 128>(p, batch, st) : launch_decode_g<bf16_t, 64>(p, batch, st);
   else
     rc = head_dim == 128 ? launch_decode_g<f16_t, 128>(p, batch, st) : launch_decode_g<f16_t, 64>(p, batch, st);
@@ -446,14 +505,14 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
     const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
     if (dtype == MI_BF16) {
       if (head_dim == 128)
-        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
+        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
       else
-        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
+        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
     } else {
       if (head_dim == 128)
-        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
+        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
       else
-        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale);
+        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
     }
     MI_CHECK_LAUNCH();
   }
@@ -482,4 +541,15 @@ extern "C" int mi_decode_attn_fp8out(const void* q, const void* k_buf, const voi
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
                           stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
                           stream, o_fp8, o_scale);
+}
+
+extern "C" int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                                    void* o_fp8 /* nullable */, const float* o_scale, float k_scale, float v_scale,
+                                    const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace, int64_t batch,
+                                    int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                                    int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                                    float logit_cap, int64_t num_splits, int dtype, void* stream) {
+  return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stream, o_fp8, o_scale, true, k_scale, v_scale);
 }

@@ -162,3 +162,70 @@ extern "C" int mi_kv_write(void* k_cache, void* v_cache, const int64_t* loc, con
   MI_CHECK_LAUNCH();
   return MI_OK;
 }
+
+// ---------------------------------------------------------------- kv_write into an fp8 (e4m3fn) pool
+// set_kv_buffer for an fp8 KV cache (memory_pool.py:432-440): cache_k.div_(k_scale) on the T-typed rows
+// (on the GPU torch multiplies by the fp32 reciprocal, BinaryDivTrueKernel.cu; the result is rounded to T),
+// then .to(fp8).  Deviation: values beyond +-448 saturate (torch's cast produces NaN).
+// One wave per (token, k|v) row, 8 elements (16 B in, 8 B out) per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void kv_write_fp8_kernel(uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache,
+                                                           const int64_t* __restrict__ loc, const T* __restrict__ k,
+                                                           const T* __restrict__ v, int64_t tokens, int64_t row_k,
+                                                           int64_t row_v, int64_t cs_k, int64_t cs_v, int64_t ss_k,
+                                                           int64_t ss_v, float inv_k, float inv_v) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= tokens * 2) return;
+  const int64_t t = w >> 1;
+  const bool is_v = w & 1;
+  const int64_t slot = loc[t];
+  const T* src = is_v ? v + t * ss_v : k + t * ss_k;
+  uint8_t* dst = is_v ? v_cache + slot * cs_v : k_cache + slot * cs_k;
+  const int64_t n = is_v ? row_v : row_k;
+  const float inv = is_v ? inv_v : inv_k;
+  for (int64_t i = lane; i < n / 8; i += 64) {
+    const uint4 u = *(const uint4*)(src + i * 8);
+    const uint32_t wd[4] = {u.x, u.y, u.z, u.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = Elem<T>::lo(wd[j]);
+      f[2 * j + 1] = Elem<T>::hi(wd[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (inv != 1.0f) f[j] = round_to<T>(f[j] * inv);
+      f[j] = fmaxf(fminf(f[j], 448.0f), -448.0f);
+    }
+    uint32_t lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *(uint2*)(dst + i * 8) = make_uint2(lo, hi);
+  }
+}
+
+extern "C" int mi_kv_write_fp8(void* k_cache, void* v_cache, const int64_t* loc, const void* k, const void* v,
+                               int64_t tokens, int64_t row_elems_k, int64_t row_elems_v, int64_t cache_stride_k,
+                               int64_t cache_stride_v, int64_t src_stride_k, int64_t src_stride_v, float k_scale,
+                               float v_scale, int dtype, void* stream) {
+  MI_CHECK_ARG(tokens >= 0);
+  if (tokens == 0) return MI_OK;
+  MI_CHECK_ARG(k_cache && v_cache && loc && k && v);
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
+  MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
+  if (row_elems_k % 8 || row_elems_v % 8 || cache_stride_k % 8 || cache_stride_v % 8 || src_stride_k % 8 || src_stride_v % 8 ||
+      (((uintptr_t)k_cache | (uintptr_t)v_cache) & 7) || (((uintptr_t)k | (uintptr_t)v) & 15))
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_kv_write_fp8: rows must be multiples of 8 elements and 16-byte aligned");
+  const float inv_k = k_scale == 1.0f ? 1.0f : 1.0f / k_scale, inv_v = v_scale == 1.0f ? 1.0f : 1.0f / v_scale;
+  const int64_t waves = tokens * 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_BF16)
+    kv_write_fp8_kernel<bf16_t><<<(unsigned)cdiv64(waves, 4), 256, 0, st>>>((uint8_t*)k_cache, (uint8_t*)v_cache, loc, (const bf16_t*)k, (const bf16_t*)v, tokens, row_elems_k, row_elems_v, cache_stride_k, cache_stride_v, src_stride_k, src_stride_v, inv_k, inv_v);
+  else
+    kv_write_fp8_kernel<f16_t><<<(unsigned)cdiv64(waves, 4), 256, 0, st>>>((uint8_t*)k_cache, (uint8_t*)v_cache, loc, (const f16_t*)k, (const f16_t*)v, tokens, row_elems_k, row_elems_v, cache_stride_k, cache_stride_v, src_stride_k, src_stride_v, inv_k, inv_v);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}

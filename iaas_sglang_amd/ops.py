@@ -85,6 +85,23 @@ def kv_write(k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor, k:
                           _stream()), "mi_kv_write")
 
 
+def kv_write_fp8(k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                 k_scale: Optional[float] = None, v_scale: Optional[float] = None) -> None:
+    """fp8 pool (uint8 or float8_e4m3fn storage): cache[loc] = fp8(k / k_scale), fp8(v / v_scale)."""
+    assert loc.dtype == torch.int64 and loc.is_contiguous()
+    T = loc.shape[0]
+    k = k.reshape(T, -1)
+    v = v.reshape(T, -1)
+    assert k.dtype == v.dtype and k.stride(1) == 1 and v.stride(1) == 1
+    assert k_cache.element_size() == 1 and v_cache.element_size() == 1
+    assert k_cache[0].numel() == k.shape[1] and v_cache[0].numel() == v.shape[1]
+    assert k_cache[0].is_contiguous() and v_cache[0].is_contiguous()
+    check(lib.mi_kv_write_fp8(_ptr(k_cache), _ptr(v_cache), _ptr(loc), _ptr(k), _ptr(v), T, k.shape[1], v.shape[1],
+                              k_cache.stride(0), v_cache.stride(0), k.stride(0), v.stride(0),
+                              float(1.0 if k_scale is None else k_scale), float(1.0 if v_scale is None else v_scale),
+                              _dt(k), _stream()), "mi_kv_write_fp8")
+
+
 # --------------------------------------------------------------------- attention
 def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_splits: int) -> int:
     return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4
@@ -345,6 +362,34 @@ def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.T
                                     float(sm_scale), float(logit_cap), int(num_splits), _dt(q), _stream()),
           "mi_decode_attn_fp8out")
     return o_fp8
+
+
+def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.Tensor, kv_indptr_t: torch.Tensor,
+                           kv_indices_t: torch.Tensor, sm_scale: float, k_scale: float = 1.0, v_scale: float = 1.0,
+                           logit_cap: float = 0.0, num_splits: int = 1, workspace: Optional[torch.Tensor] = None,
+                           o: Optional[torch.Tensor] = None, o_fp8: Optional[torch.Tensor] = None,
+                           o_scale: Optional[torch.Tensor] = None):
+    """Decode attention over an fp8 (e4m3fn / uint8 storage) KV pool [slots, Hkv, 128]."""
+    B, Hq, D = q.shape
+    Hkv = k_buf8.shape[1]
+    assert k_buf8.element_size() == 1 and v_buf8.element_size() == 1 and k_buf8.shape[2] == D and v_buf8.shape[2] == D
+    assert q.stride(2) == 1 and q.stride(1) == D
+    assert k_buf8.stride(2) == 1 and k_buf8.stride(1) == D and v_buf8.stride(2) == 1 and v_buf8.stride(1) == D
+    assert o is not None or o_fp8 is not None
+    if o is not None:
+        assert o.dtype == q.dtype and o.stride(2) == 1 and o.stride(1) == D
+    if o_fp8 is not None:
+        assert o_fp8.dtype == FP8_DTYPE and o_fp8.is_contiguous() and o_scale is not None and o_scale.dtype == torch.float32
+    if num_splits > 1:
+        need = decode_workspace_numel(B, Hq, D, num_splits)
+        assert workspace is not None and workspace.dtype == torch.float32 and workspace.numel() >= need
+    check(lib.mi_decode_attn_fp8kv(_ptr(q), _ptr(k_buf8), _ptr(v_buf8), _ptr(o), _ptr(o_fp8), _ptr(o_scale),
+                                   float(k_scale), float(v_scale), _ptr(kv_indptr_t), _ptr(kv_indices_t),
+                                   _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
+                                   o.stride(0) if o is not None else Hq * D, k_buf8.stride(0), v_buf8.stride(0),
+                                   float(sm_scale), float(logit_cap), int(num_splits), _dt(q), _stream()),
+          "mi_decode_attn_fp8kv")
+    return o if o is not None else o_fp8
 
 
 def _fused_ws(M: int, N: int, K: int, device):

@@ -64,6 +64,16 @@ int mi_kv_write(void* k_cache, void* v_cache, const int64_t* loc, const void* k,
                 int64_t src_stride_k, int64_t src_stride_v,     /* elements between tokens  */
                 int dtype, void* stream);
 
+/* The same scatter into an fp8 (e4m3fn, stored as bytes) pool: row = sat(round_T(row * (1/scale))) -> fp8.
+ * k_scale / v_scale = 1 means a plain cast (what the reference's Triton backend stores).
+ * replaces: MHATokenToKVPool.set_kv_buffer with an fp8 cache dtype, mem_cache/memory_pool.py:432-455
+ * (cache_k.div_(k_scale); cache_k.to(fp8); index_put).  Values beyond +-448 saturate (torch: NaN). */
+int mi_kv_write_fp8(void* k_cache, void* v_cache, const int64_t* loc, const void* k, const void* v,
+                    int64_t tokens, int64_t row_elems_k, int64_t row_elems_v,
+                    int64_t cache_stride_k, int64_t cache_stride_v, /* BYTES between slots      */
+                    int64_t src_stride_k, int64_t src_stride_v,     /* elements between tokens  */
+                    float k_scale, float v_scale, int dtype /* of k, v */, void* stream);
+
 /* ------------------------------------------------------------------- attention */
 
 /* bytes of fp32 workspace mi_decode_attn needs for (batch, Hq, Dv, num_splits) */
@@ -96,6 +106,19 @@ int mi_decode_attn_fp8out(const void* q, const void* k_buf, const void* v_buf, v
                           int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                           int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot,
                           float sm_scale, float logit_cap, int64_t num_splits, int dtype, void* stream);
+
+/* mi_decode_attn over an fp8 (e4m3fn) KV pool: k_buf/v_buf hold bytes, stride_*_slot are in BYTES, head_dim 128.
+ *   o[b,h] = v_scale * softmax_j(sm_scale * k_scale * q[b,h] . k8[...]) . v8[...]   (K is converted up to the q
+ *   dtype for the MFMA, V to fp32; P stays fp32).  o and/or o_fp8 (+ o_scale) as in mi_decode_attn_fp8out.
+ * replaces: decode attention over an fp8 MHATokenToKVPool (memory_pool.py:113-117,389-405) with the k/v scale
+ * convention of flashinfer_backend.py:474-555; halves the algorithmic bytes of the decode step. */
+int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                         void* o_fp8 /* nullable */, const float* o_scale, float k_scale, float v_scale,
+                         const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace,
+                         int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                         int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_k_slot,
+                         int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
+                         int dtype, void* stream);
 
 /* Ragged extend (prefill-with-prefix) attention.
  *   q_ext [E,Hq,D], k_ext/v_ext [E,Hkv,D] : the new tokens, request i owns rows

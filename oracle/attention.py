@@ -234,3 +234,30 @@ def merge_state(o_a, lse_a, o_b, lse_b):
     se = pa + pb
     out = o_a.float() * (pa / se).unsqueeze(-1) + o_b.float() * (pb / se).unsqueeze(-1)
     return out.to(o_a.dtype), torch.log(se) + m
+
+
+# ---------------------------------------------------------------------------
+# fp8 (e4m3fn) KV cache -- SURVEY 8f row 1.  PARITY UNPINNED by reference-run vectors: the torch-native
+# oracle backend cannot read an fp8 pool; the arithmetic below restates the CONVENTION of the backends that
+# do (flashinfer_backend.py:474-555, flashattention_backend.py:643-671: store k / k_scale, attend with
+# k_descale / v_descale) on top of MHATokenToKVPool.set_kv_buffer (memory_pool.py:432-440).
+# ---------------------------------------------------------------------------
+def set_kv_buffer_fp8(k_cache8, v_cache8, loc, k, v, k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+    """k_cache8/v_cache8: float8_e4m3fn [slots, Hkv, D].  cache_k.div_(k_scale) on the T-typed rows (the GPU
+    kernel torch dispatches multiplies by the fp32 reciprocal and rounds to T), then .to(fp8); values beyond
+    +-448 saturate here and in the HIP kernel (torch's own cast would give NaN)."""
+    def q8(x, scale):
+        if scale != 1.0:
+            inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(scale, dtype=torch.float32)
+            x = (x.float() * inv).to(x.dtype)
+        return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    k_cache8[loc] = q8(k.reshape(loc.shape[0], *k_cache8.shape[1:]), k_scale)
+    v_cache8[loc] = q8(v.reshape(loc.shape[0], *v_cache8.shape[1:]), v_scale)
+
+
+def decode_fp32_fp8kv(q, k_cache8, v_cache8, req_to_token, req_pool_indices, seq_lens, scaling,
+                      k_scale: float = 1.0, v_scale: float = 1.0, logit_cap: float = 0.0):
+    """softmax(scaling * k_scale * q . k8) . v8 * v_scale, everything in fp32 (decode_fp32 on the dequantised pool)."""
+    kf = k_cache8.float() * k_scale
+    vf = v_cache8.float() * v_scale
+    return decode_fp32(q, kf, vf, req_to_token, req_pool_indices, seq_lens, scaling, logit_cap=logit_cap)
