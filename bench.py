@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-custom-ar", action="store_true", help="TP>1: use RCCL only (skip the native xGMI all-reduce)")
     ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
     ap.add_argument("--prefill-batch", type=int, default=8, help="sequences of --seq tokens in the prefill leg (0 = skip)")
+    ap.add_argument("--kv-dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="KV cache dtype: bf16 is BASELINE.json's configuration (the headline); fp8 = e4m3fn pool "
+                         "(SURVEY 8f row 1), reported as a variant -- a different workload, not the headline")
     ap.add_argument("--kernel-reps", type=int, default=3, help="passes over all layers for the roofline timing")
     return ap.parse_args()
 
@@ -107,9 +110,9 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def attention_bytes(B, S, Hkv, D, Hq, esize=2):
+def attention_bytes(B, S, Hkv, D, Hq, esize=2, kv_esize=None):
     """Algorithmic bytes of ONE decode-attention launch: K+V rows once, q, o, kv_indices."""
-    return 2 * B * S * Hkv * D * esize + 2 * B * Hq * D * esize + 4 * B * S
+    return 2 * B * S * Hkv * D * (kv_esize or esize) + 2 * B * Hq * D * esize + 4 * B * S
 
 
 def time_attention_kernel(stack, runner, backend, fb, reps):
@@ -123,10 +126,17 @@ def time_attention_kernel(stack, runner, backend, fb, reps):
     md = backend.forward_metadata
     pool = runner.token_to_kv_pool
 
+    fp8_pool = pool.get_key_buffer(0).element_size() == 1
+
     def one_pass():
         for li in range(s.layers):
-            ops.decode_attention(q, pool.get_key_buffer(li), pool.get_value_buffer(li), o, md.kv_indptr,
-                                 md.kv_indices, s.head_dim ** -0.5, 0.0, md.num_kv_splits, md.workspace)
+            if fp8_pool:
+                ops.decode_attention_fp8kv(q, pool.get_key_buffer(li), pool.get_value_buffer(li), md.kv_indptr,
+                                           md.kv_indices, s.head_dim ** -0.5, 1.0, 1.0, 0.0, md.num_kv_splits,
+                                           md.workspace, o=o)
+            else:
+                ops.decode_attention(q, pool.get_key_buffer(li), pool.get_value_buffer(li), o, md.kv_indptr,
+                                     md.kv_indices, s.head_dim ** -0.5, 0.0, md.num_kv_splits, md.workspace)
 
     one_pass()
     stream = torch.cuda.current_stream()
@@ -261,8 +271,10 @@ def main():
     if a.splits:
         os.environ["MI_ATTN_MAX_KV_SPLITS"] = str(a.splits)
 
+    kv8 = a.kv_dtype == "fp8"
     runner = H.make_runner(shape, max_reqs=B, ctx=S + 8, pool_tokens=B * S, dtype=dtype, device=dev, tp=tp,
-                           fill_kv=True, seed=rank, max_kv_splits=a.splits or 8)
+                           fill_kv=True, seed=rank, max_kv_splits=a.splits or 8,
+                           kv_dtype=torch.float8_e4m3fn if kv8 else None)
     backend = MiAttnBackend(runner)
     if a.splits:
         backend._choose_splits = lambda bs, tot: a.splits
@@ -320,14 +332,14 @@ def main():
     # ---- roofline of the dominant kernel (decode attention), measured live with HIP events
     Hq, Hkv, D = stack.Hq, stack.Hkv, shape.head_dim
     t_attn = time_attention_kernel(stack, runner, backend, fb, a.kernel_reps)
-    abytes = attention_bytes(B, S, Hkv, D, Hq)
+    abytes = attention_bytes(B, S, Hkv, D, Hq, kv_esize=1 if kv8 else 2)
     achieved = abytes / t_attn / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "decode_attn_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("batch") == B and tj.get("seq") == S and tj.get("tp") == tp:
+            if tj.get("batch") == B and tj.get("seq") == S and tj.get("tp") == tp and not kv8:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -341,13 +353,13 @@ def main():
         except Exception as e:   # the decode number must not be lost to a prefill-side problem
             prefill = {"error": f"{type(e).__name__}: {e}"}
     result = {
-        "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)",
+        "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)" + (" [variant: fp8 KV cache]" if kv8 else ""),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), bf16 KV/f32 softmax (attention)",
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), " + ("fp8 e4m3" if kv8 else "bf16") + " KV/f32 softmax (attention)",
         "data": "synthetic",
         "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears ({a.act_scheme} activation scale), "
-                               f"bf16 paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
+                               f"{'fp8 e4m3' if kv8 else 'bf16'} paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
                    "all_reduce": None if tp == 1 else ("native-xgmi" if custom_ar is not None else "rccl"),

@@ -56,28 +56,25 @@ class AttnLayer:
         self.k_scale = self.v_scale = None
 
 
-class KVPool:
-    """MHATokenToKVPool's data contract (mem_cache/memory_pool.py:236-249): per layer
-    [size + page_size, Hkv, D], slot 0 is the padding sink."""
-
-    def __init__(self, size, layer_num, head_num, head_dim, dtype, device, fill_random=False, seed=0):
-        self.size, self.dtype = size, dtype
-        g = torch.Generator(device=device).manual_seed(seed) if fill_random else None
-        self.k_buffer, self.v_buffer = [], []
-        for _ in range(layer_num):
-            for bufs in (self.k_buffer, self.v_buffer):
-                if fill_random:
-                    t = torch.empty(size + 1, head_num, head_dim, dtype=dtype, device=device)
-                    t.normal_(generator=g)
+def make_kv_pool(size, layer_num, head_num, head_dim, dtype, device, fill_random=False, seed=0, kv_dtype=None):
+    """MHATokenToKVPool (mem_cache/memory_pool.py:176-260), optionally pre-filled with N(0,1) data so that a
+    steady-state decode batch can be benchmarked without running the prefill first."""
+    from .mem_cache import MHATokenToKVPool
+    pool = MHATokenToKVPool(size, 1, kv_dtype or dtype, head_num, head_dim, layer_num, device)
+    if fill_random:
+        g = torch.Generator(device=device).manual_seed(seed)
+        for bufs in zip(pool.k_buffer, pool.v_buffer):
+            for t in bufs:
+                if t.dtype == torch.uint8:      # fp8 pool: N(0,1) values stored as e4m3fn bytes, filled in chunks
+                    rows = t.shape[0]
+                    step = max(1, (1 << 26) // (head_num * head_dim))
+                    for r0 in range(0, rows, step):
+                        blk = torch.empty(min(step, rows - r0), head_num, head_dim, dtype=torch.float32, device=device)
+                        blk.normal_(generator=g)
+                        t[r0:r0 + blk.shape[0]] = blk.to(torch.float8_e4m3fn).view(torch.uint8)
                 else:
-                    t = torch.zeros(size + 1, head_num, head_dim, dtype=dtype, device=device)
-                bufs.append(t)
-
-    def get_key_buffer(self, layer_id):
-        return self.k_buffer[layer_id]
-
-    def get_value_buffer(self, layer_id):
-        return self.v_buffer[layer_id]
+                    t.normal_(generator=g)
+    return pool
 
 
 class Linear(torch.nn.Module):
@@ -114,19 +111,23 @@ class Linear(torch.nn.Module):
 
 
 def make_runner(shape: ModelShape, max_reqs, ctx, pool_tokens, dtype, device, tp=1, fill_kv=False, seed=0,
-                max_kv_splits=8):
+                max_kv_splits=8, kv_dtype=None):
     """MockModelRunner-equivalent namespace (test_flashattn_backend.py:15-69, SURVEY 8b list)."""
     Hkv = max(1, shape.num_kv_heads // tp)
     mc = SimpleNamespace(num_attention_heads=shape.num_heads, num_key_value_heads=shape.num_kv_heads,
                          context_len=ctx, head_dim=shape.head_dim, is_encoder_decoder=False,
                          get_num_kv_heads=lambda tp_size: max(1, shape.num_kv_heads // tp_size))
-    r2t = SimpleNamespace(size=max_reqs, req_to_token=torch.zeros(max_reqs, ctx, dtype=torch.int32, device=device))
-    pool = KVPool(pool_tokens, shape.layers, Hkv, shape.head_dim, dtype, device, fill_random=fill_kv, seed=seed)
+    from .mem_cache import ReqToTokenPool, TokenToKVPoolAllocator
+    r2t = ReqToTokenPool(max_reqs, ctx, device)
+    pool = make_kv_pool(pool_tokens, shape.layers, Hkv, shape.head_dim, dtype, device, fill_random=fill_kv, seed=seed,
+                        kv_dtype=kv_dtype)
+    allocator = TokenToKVPoolAllocator(pool_tokens, pool.dtype, device, pool)
     sa = SimpleNamespace(triton_attention_num_kv_splits=max_kv_splits, page_size=1,
                          speculative_num_draft_tokens=None, speculative_num_steps=None)
     return SimpleNamespace(device=device, dtype=dtype, model_config=mc, req_to_token_pool=r2t,
-                           token_to_kv_pool=pool, sliding_window_size=None, server_args=sa, tp_size=tp, gpu_id=0,
-                           kv_cache_dtype="auto", page_size=1)
+                           token_to_kv_pool=pool, token_to_kv_pool_allocator=allocator, sliding_window_size=None,
+                           server_args=sa, tp_size=tp, gpu_id=0,
+                           kv_cache_dtype="auto" if kv_dtype is None else "fp8_e4m3", page_size=1)
 
 
 def rope_cache(head_dim, max_pos, base, device):
@@ -246,10 +247,19 @@ class LlamaStack:
         L0 = self.layers[0]
         qx = ops.rmsnorm_fp8(hidden, L0.input_norm, s.rms_eps, L0.qkv.input_scale)
         x = None
+        fp8_pool = pool.get_key_buffer(0).element_size() == 1
         for i, L in enumerate(self.layers):
-            q = L.qkv.quant_method.apply_rope_kvwrite(L.qkv, qx, positions, self.cos_sin, pool.get_key_buffer(i),
-                                                      pool.get_value_buffer(i), fb.out_cache_loc, self.Hq, self.Hkv, D)
-            a8 = backend.forward(q, None, None, L.attn, fb, save_kv_cache=False, fp8_out_scale=L.o.input_scale)
+            if fp8_pool:   # the fused rope + kv-write consumer stores T-typed rows: fp8 pools take the scatter kernel
+                qkv = L.qkv.forward_prequantized(qx, self.dtype)
+                q, k, v = (qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size],
+                           qkv[:, self.q_size + self.kv_size:])
+                ops.rope_neox_(q, k, positions, self.cos_sin, D)
+                a8 = backend.forward(q, k.reshape(-1, self.Hkv, D), v.reshape(-1, self.Hkv, D), L.attn, fb,
+                                     fp8_out_scale=L.o.input_scale)
+            else:
+                q = L.qkv.quant_method.apply_rope_kvwrite(L.qkv, qx, positions, self.cos_sin, pool.get_key_buffer(i),
+                                                          pool.get_value_buffer(i), fb.out_cache_loc, self.Hq, self.Hkv, D)
+                a8 = backend.forward(q, None, None, L.attn, fb, save_kv_cache=False, fp8_out_scale=L.o.input_scale)
             if self.tp == 1:
                 _, qx = L.o.quant_method.apply_add_rmsnorm(L.o, a8, residual, L.post_norm, s.rms_eps,
                                                            L.gate_up.input_scale)
