@@ -26,6 +26,8 @@ SIGNATURES = {
     "mi_kv_indices": (_int, [_p, _i64, _p, _p, _int, _p, _p, _p, _i64, _p]),
     "mi_kv_write": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_kv_write_fp8": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _int, _p]),
+    "mi_alloc_extend": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "mi_alloc_decode": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _f, _f, _i64, _int, _p]),

@@ -229,3 +229,110 @@ extern "C" int mi_kv_write_fp8(void* k_cache, void* v_cache, const int64_t* loc,
   MI_CHECK_LAUNCH();
   return MI_OK;
 }
+
+// ---------------------------------------------------------------- paged slot allocation (scheduler side)
+// alloc_extend / alloc_decode of PagedTokenToKVPoolAllocator (mem_cache/allocator.py:278-404, Triton there):
+// request i gets (seq_lens[i] - prefix_lens[i]) slot indices: first the rest of its old partial page
+// (last_loc + 1 ...), then whole new pages, then the head of one more new page; new pages are taken from the
+// front of free_pages in request order.  Integer, bit-exact.  The reference recomputes the prefix sums in
+// every program (O(bs^2)); here ONE workgroup scans once into `scratch`, then one workgroup per request fills.
+__global__ __launch_bounds__(256) void alloc_scan_kernel(const int64_t* __restrict__ pre_lens /* null: decode */,
+                                                         const int64_t* __restrict__ seq_lens, int64_t bs, int64_t ps,
+                                                         int64_t* __restrict__ scratch /* [2*bs]: out start, page start */,
+                                                         int64_t* __restrict__ ret, int merged_ret) {
+  __shared__ int64_t wsum[2][4];
+  __shared__ int64_t carry[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+  __syncthreads();
+  for (int64_t base = 0; base < bs; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    int64_t ext = 0, pages = 0;
+    if (i < bs) {
+      const int64_t s = seq_lens[i], p = pre_lens ? pre_lens[i] : s - 1;
+      ext = s - p;
+      pages = (s + ps - 1) / ps - (p + ps - 1) / ps;
+    }
+    int64_t ie = ext, ip = pages;   // inclusive scans inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t te = __shfl_up(ie, off), tp = __shfl_up(ip, off);
+      if (lane >= off) { ie += te; ip += tp; }
+    }
+    if (lane == 63) { wsum[0][wave] = ie; wsum[1][wave] = ip; }
+    __syncthreads();
+    int64_t oe = carry[0], op = carry[1];
+    for (int w = 0; w < wave; ++w) { oe += wsum[0][w]; op += wsum[1][w]; }
+    if (i < bs) { scratch[i] = oe + ie - ext; scratch[bs + i] = op + ip - pages; }
+    __syncthreads();
+    if (threadIdx.x == 255) { carry[0] = oe + ie; carry[1] = op + ip; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ret = merged_ret ? ((carry[1] << 32) | carry[0]) : carry[1];
+}
+
+__global__ __launch_bounds__(256) void alloc_extend_fill_kernel(const int64_t* __restrict__ pre_lens,
+                                                                const int64_t* __restrict__ seq_lens,
+                                                                const int64_t* __restrict__ last_loc,
+                                                                const int64_t* __restrict__ free_pages,
+                                                                const int64_t* __restrict__ scratch, int64_t bs, int64_t ps,
+                                                                int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  const int64_t p = pre_lens[i], s = seq_lens[i];
+  const int64_t pos = scratch[i], page = scratch[bs + i];
+  const int64_t ceil_pre = (p + ps - 1) / ps;
+  const int64_t new_pages = (s + ps - 1) / ps - ceil_pre;
+  const int64_t n1 = min(s, ceil_pre * ps) - p;
+  const int64_t n2 = (p + n1 != s) ? s / ps * ps - ceil_pre * ps : 0;
+  const int64_t n3 = (p + n1 != s && p + n1 + n2 != s) ? s - s / ps * ps : 0;
+  const int64_t ll = last_loc[i];
+  for (int64_t j = threadIdx.x; j < s - p; j += 256) {
+    int64_t v;
+    if (j < n1) v = ll + 1 + j;
+    else if (j < n1 + n2) v = free_pages[page + (j - n1) / ps] * ps + (j - n1) % ps;
+    else v = free_pages[page + new_pages - 1] * ps + (j - n1 - n2);
+    out[pos + j] = v;
+  }
+  (void)n3;
+}
+
+__global__ __launch_bounds__(256) void alloc_decode_fill_kernel(const int64_t* __restrict__ seq_lens,
+                                                                const int64_t* __restrict__ last_loc,
+                                                                const int64_t* __restrict__ free_pages,
+                                                                const int64_t* __restrict__ scratch, int64_t bs, int64_t ps,
+                                                                int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= bs) return;
+  const int64_t s = seq_lens[i];
+  const int64_t need = (s + ps - 1) / ps - (s - 1 + ps - 1) / ps;
+  out[i] = need == 0 ? last_loc[i] + 1 : free_pages[scratch[bs + i]] * ps;
+}
+
+extern "C" int mi_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                               const int64_t* free_pages, int64_t* out_indices, int64_t* ret_value, int64_t* scratch,
+                               int64_t batch, int64_t page_size, void* stream) {
+  MI_CHECK_ARG(batch >= 0 && page_size >= 1);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(prefix_lens && seq_lens && last_loc && free_pages && out_indices && ret_value && scratch);
+  MI_CHECK_ARG(batch <= 0x7fffffff);
+  hipStream_t st = (hipStream_t)stream;
+  alloc_scan_kernel<<<1, 256, 0, st>>>(prefix_lens, seq_lens, batch, page_size, scratch, ret_value, 1);
+  MI_CHECK_LAUNCH();
+  alloc_extend_fill_kernel<<<(unsigned)batch, 256, 0, st>>>(prefix_lens, seq_lens, last_loc, free_pages, scratch, batch, page_size, out_indices);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+extern "C" int mi_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                               int64_t* out_indices, int64_t* ret_value, int64_t* scratch, int64_t batch,
+                               int64_t page_size, void* stream) {
+  MI_CHECK_ARG(batch >= 0 && page_size >= 1);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(seq_lens && last_loc && free_pages && out_indices && ret_value && scratch);
+  hipStream_t st = (hipStream_t)stream;
+  alloc_scan_kernel<<<1, 256, 0, st>>>(nullptr, seq_lens, batch, page_size, scratch, ret_value, 0);
+  MI_CHECK_LAUNCH();
+  alloc_decode_fill_kernel<<<(unsigned)cdiv64(batch, 256), 256, 0, st>>>(seq_lens, last_loc, free_pages, scratch, batch, page_size, out_indices);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}

@@ -171,3 +171,61 @@ class TokenToKVPoolAllocator:
 
     def alloc_decode(self, *args, **kwargs):
         raise NotImplementedError("alloc_decode is only for paged allocator")
+
+
+class PagedTokenToKVPoolAllocator(TokenToKVPoolAllocator):
+    """allocator.py:407-543: page-aligned allocation; `alloc_extend` / `alloc_decode` are our integer kernels
+    (mi_alloc_extend / mi_alloc_decode) instead of the reference's Triton kernels."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, device: str, kvcache: MHATokenToKVPool):
+        self.num_pages = size // page_size
+        super().__init__(size, dtype, device, kvcache)
+        self.page_size = page_size
+        self.ret_values = torch.empty((1,), dtype=torch.int64, device=self.device)
+
+    def clear(self):
+        # the padded slot 0 (page 0) is used for writing dummy outputs from padded tokens
+        self.free_pages = torch.arange(1, self.num_pages + 1, dtype=torch.int64, device=self.device)
+        self.is_not_in_free_group = True
+        self.free_group = []
+
+    def available_size(self) -> int:
+        return len(self.free_pages) * self.page_size
+
+    def alloc(self, need_size: int) -> Optional[torch.Tensor]:
+        num_pages = need_size // self.page_size
+        if num_pages > len(self.free_pages):
+            return None
+        out_pages = self.free_pages[:num_pages]
+        self.free_pages = self.free_pages[num_pages:]
+        return (out_pages[:, None] * self.page_size + torch.arange(self.page_size, device=self.device)).reshape(-1)
+
+    def alloc_extend(self, prefix_lens: torch.Tensor, seq_lens: torch.Tensor, last_loc: torch.Tensor,
+                     extend_num_tokens: int) -> Optional[torch.Tensor]:
+        out_indices = torch.empty((extend_num_tokens,), dtype=torch.int64, device=self.device)
+        ops.alloc_extend(prefix_lens, seq_lens, last_loc, self.free_pages.contiguous(), out_indices, self.ret_values,
+                         self.page_size)
+        num_new_pages = int(self.ret_values.item()) >> 32           # the reference syncs here too (allocator.py:482)
+        if num_new_pages > len(self.free_pages):
+            return None
+        self.free_pages = self.free_pages[num_new_pages:]
+        return out_indices
+
+    def alloc_decode(self, seq_lens: torch.Tensor, last_loc: torch.Tensor) -> Optional[torch.Tensor]:
+        bs = len(seq_lens)
+        out_indices = torch.empty((bs,), dtype=torch.int64, device=self.device)
+        ops.alloc_decode(seq_lens, last_loc, self.free_pages.contiguous(), out_indices, self.ret_values, self.page_size)
+        num_new_pages = int(self.ret_values.item())
+        if num_new_pages > len(self.free_pages):
+            return None
+        self.free_pages = self.free_pages[num_new_pages:]
+        return out_indices
+
+    def free(self, free_index: torch.Tensor):
+        if free_index.numel() == 0:
+            return
+        if self.is_not_in_free_group:
+            free_page_indices = torch.unique(free_index // self.page_size)
+            self.free_pages = torch.cat((free_page_indices, self.free_pages))     # freed pages go to the FRONT (:531-532)
+        else:
+            self.free_group.append(free_index)

@@ -102,6 +102,27 @@ def kv_write_fp8(k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor
                               _dt(k), _stream()), "mi_kv_write_fp8")
 
 
+def alloc_extend(prefix_lens: torch.Tensor, seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: torch.Tensor,
+                 out_indices: torch.Tensor, ret_value: torch.Tensor, page_size: int) -> None:
+    """Paged slot allocation for an extend batch (all int64 device tensors); ret_value [1] = pages<<32 | tokens."""
+    for t in (prefix_lens, seq_lens, last_loc, free_pages, out_indices, ret_value):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    bs = prefix_lens.shape[0]
+    scratch = torch.empty(2 * max(bs, 1), dtype=torch.int64, device=prefix_lens.device)
+    check(lib.mi_alloc_extend(_ptr(prefix_lens), _ptr(seq_lens), _ptr(last_loc), _ptr(free_pages), _ptr(out_indices),
+                              _ptr(ret_value), _ptr(scratch), bs, int(page_size), _stream()), "mi_alloc_extend")
+
+
+def alloc_decode(seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: torch.Tensor, out_indices: torch.Tensor,
+                 ret_value: torch.Tensor, page_size: int) -> None:
+    for t in (seq_lens, last_loc, free_pages, out_indices, ret_value):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    bs = seq_lens.shape[0]
+    scratch = torch.empty(2 * max(bs, 1), dtype=torch.int64, device=seq_lens.device)
+    check(lib.mi_alloc_decode(_ptr(seq_lens), _ptr(last_loc), _ptr(free_pages), _ptr(out_indices), _ptr(ret_value),
+                              _ptr(scratch), bs, int(page_size), _stream()), "mi_alloc_decode")
+
+
 # --------------------------------------------------------------------- attention
 def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_splits: int) -> int:
     return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4

@@ -74,6 +74,19 @@ int mi_kv_write_fp8(void* k_cache, void* v_cache, const int64_t* loc, const void
                     int64_t src_stride_k, int64_t src_stride_v,     /* elements between tokens  */
                     float k_scale, float v_scale, int dtype /* of k, v */, void* stream);
 
+/* Paged slot allocation (scheduler side, page_size >= 1).  Request i receives seq_lens[i] - prefix_lens[i] slot
+ * indices at out_indices[sum_{j<i} extend_j ...]: the rest of its old partial page (last_loc[i] + 1 ...), whole
+ * new pages, then the head of one more new page; new pages come from the front of free_pages in request order.
+ * *ret_value = (num_new_pages << 32) | sum_extend_lens (extend) / num_new_pages (decode): the caller checks it
+ * against len(free_pages) and drops that many pages.  scratch: int64 [2 * batch].  All tensors int64.
+ * replaces: alloc_extend_kernel / alloc_decode_kernel, mem_cache/allocator.py:278-404 (bit-exact). */
+int mi_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                    const int64_t* free_pages, int64_t* out_indices, int64_t* ret_value, int64_t* scratch,
+                    int64_t batch, int64_t page_size, void* stream);
+int mi_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                    int64_t* out_indices, int64_t* ret_value, int64_t* scratch, int64_t batch,
+                    int64_t page_size, void* stream);
+
 /* ------------------------------------------------------------------- attention */
 
 /* bytes of fp32 workspace mi_decode_attn needs for (batch, Hq, Dv, num_splits) */

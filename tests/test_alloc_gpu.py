@@ -1,0 +1,80 @@
+"""Paged slot-allocation kernels (mi_alloc_extend / mi_alloc_decode) -- integer, bit-exact against vectors produced
+by running the reference's own torch forms (tests/golden/allocator.pt) and against oracle/alloc.py."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import alloc as oal  # noqa: E402
+
+DEV = "cuda"
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), "golden", "allocator.pt"), weights_only=True)
+
+
+@pytest.mark.parametrize("idx", range(12))
+def test_alloc_kernels_equal_reference_vectors(idx):
+    from iaas_sglang_amd import ops
+    c = GOLD["paged_cases"][idx]
+    ret = torch.zeros(1, dtype=torch.int64, device=DEV)
+    out = torch.full_like(c["out_indices"], -7).to(DEV)
+    if c["kind"] == "extend":
+        ops.alloc_extend(c["prefix_lens"].to(DEV), c["seq_lens"].to(DEV), c["last_loc"].to(DEV), c["free_pages"].to(DEV),
+                         out, ret, c["page_size"])
+        merged = int(ret.item())
+        assert merged >> 32 == c["num_new_pages"]
+        assert merged & 0xffffffff == int((c["seq_lens"] - c["prefix_lens"]).sum())
+    else:
+        ops.alloc_decode(c["seq_lens"].to(DEV), c["last_loc"].to(DEV), c["free_pages"].to(DEV), out, ret, c["page_size"])
+        assert int(ret.item()) == c["num_new_pages"]
+    assert torch.equal(out.cpu(), c["out_indices"])
+
+
+@pytest.mark.parametrize("page_size,bs", [(8, 3), (16, 700), (1, 300), (128, 40)])
+def test_alloc_extend_vs_oracle_including_partial_page_only_extensions(page_size, bs):
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(page_size + bs)
+    prefix = torch.randint(0, 4 * page_size + 1, (bs,), generator=g)
+    ext = torch.randint(1, 3 * page_size + 2, (bs,), generator=g)
+    ext[::3] = 1                                                     # many stay inside the old partial page
+    seq = prefix + ext
+    last_loc = torch.where(prefix > 0, torch.randint(1000, 2000, (bs,), generator=g) * page_size + (prefix - 1) % page_size,
+                           torch.full_like(prefix, -1))
+    free = torch.randperm(8192, generator=g) + 1
+    want, pages, toks = oal.alloc_extend(prefix, seq, last_loc, free, page_size)
+    out = torch.full((toks,), -7, dtype=torch.int64, device=DEV)
+    ret = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.alloc_extend(prefix.to(DEV), seq.to(DEV), last_loc.to(DEV), free.to(DEV), out, ret, page_size)
+    assert torch.equal(out.cpu(), want) and int(ret.item()) == (pages << 32 | toks)
+    # decode on top
+    seq_d, last_d = seq + 1, want[torch.cumsum(ext, 0) - 1]
+    want_d, pages_d = oal.alloc_decode(seq_d, last_d, free[pages:], page_size)
+    out_d = torch.empty(bs, dtype=torch.int64, device=DEV)
+    ops.alloc_decode(seq_d.to(DEV), last_d.to(DEV), free[pages:].contiguous().to(DEV), out_d, ret, page_size)
+    assert torch.equal(out_d.cpu(), want_d) and int(ret.item()) == pages_d
+
+
+def test_paged_allocator_class_on_device():
+    """PagedTokenToKVPoolAllocator end to end: slots of one request are page-contiguous, nothing is handed out twice,
+    exhaustion returns None without consuming pages (allocator.py:482-486)."""
+    from iaas_sglang_amd.mem_cache import PagedTokenToKVPoolAllocator
+    ps = 16
+    a = PagedTokenToKVPoolAllocator(64 * ps, ps, torch.bfloat16, DEV, None)
+    prefix = torch.tensor([0, 0, 0], dtype=torch.int64, device=DEV)
+    seq = torch.tensor([20, 16, 5], dtype=torch.int64, device=DEV)
+    last = torch.full((3,), -1, dtype=torch.int64, device=DEV)
+    idx = a.alloc_extend(prefix, seq, last, 41)
+    assert idx.shape == (41,) and len(torch.unique(idx)) == 41 and int(idx.min()) >= ps     # page 0 is never used
+    assert a.available_size() == (64 - 4) * ps                                               # 2 + 1 + 1 pages
+    r0 = idx[:20]
+    assert torch.equal(r0[:16], r0[0] + torch.arange(16, device=DEV)) and int(r0[0]) % ps == 0
+    last_loc = torch.stack([idx[19], idx[35], idx[40]])
+    d = a.alloc_decode(seq + 1, last_loc)
+    assert d.tolist()[0] == int(idx[19]) + 1 and int(d[1]) % ps == 0 and d.tolist()[2] == int(idx[40]) + 1
+    assert a.available_size() == (64 - 5) * ps
+    big = a.alloc_extend(torch.zeros(1, dtype=torch.int64, device=DEV), torch.tensor([100 * ps], device=DEV),
+                         torch.tensor([-1], device=DEV), 100 * ps)
+    assert big is None and a.available_size() == (64 - 5) * ps
+    a.free(idx)
+    assert a.available_size() == (64 - 1) * ps      # the decode token of request 1 still holds its page

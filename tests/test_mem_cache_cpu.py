@@ -68,3 +68,63 @@ def test_kv_pool_layout_and_fp8_storage():
         raise AssertionError("fp32 KV has no kernel")
     except NotImplementedError:
         pass
+
+
+# ---- pinned by vectors produced by RUNNING the reference's allocator.py (tests/golden/make_golden_alloc.py)
+import os  # noqa: E402
+
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), "golden", "allocator.pt"), weights_only=True)
+
+
+def _replay_token_allocator(a):
+    log = []
+    x = a.alloc(5); log.append(("alloc5", x.clone()))
+    log.append(("alloc9_none", torch.tensor([-1 if a.alloc(9) is None else 0])))
+    y = a.alloc(7); log.append(("alloc7", y.clone()))
+    a.free(x[1:4]); log.append(("avail", torch.tensor([a.available_size()])))
+    log.append(("alloc2", a.alloc(2).clone()))
+    a.free_group_begin(); a.free(y[:3]); a.free(x[:1]); a.free_group_end()
+    log.append(("alloc4", a.alloc(4).clone()))
+    a.clear(); log.append(("alloc12", a.alloc(12).clone()))
+    return log
+
+
+def test_token_allocator_equals_reference_run():
+    a = TokenToKVPoolAllocator(12, torch.bfloat16, "cpu", None)
+    got = _replay_token_allocator(a)
+    want = GOLD["token_allocator_log"]
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, g), (_, w) in zip(got, want):
+        assert torch.equal(g, w), n
+
+
+def test_paged_allocator_torch_parts_equal_reference_run():
+    from iaas_sglang_amd.mem_cache import PagedTokenToKVPoolAllocator
+    a = PagedTokenToKVPoolAllocator(64, 4, torch.bfloat16, "cpu", None)
+    log = []
+    x = a.alloc(12); log.append(("alloc12", x.clone()))
+    log.append(("alloc_too_many", torch.tensor([-1 if a.alloc(64) is None else 0])))
+    a.free(x[2:9]); log.append(("free_pages_after_free", a.free_pages.clone()))
+    log.append(("alloc8", a.alloc(8).clone()))
+    a.clear(); log.append(("free_pages_after_clear", a.free_pages.clone()))
+    for (n, g), (n2, w) in zip(log, GOLD["paged_log"]):
+        assert n == n2 and torch.equal(g, w), n
+    assert a.available_size() == 64
+
+
+def test_alloc_oracle_equals_reference_torch_forms():
+    """oracle/alloc.py (restatement of the Triton kernels) == the reference's own torch forms, on every golden case."""
+    from oracle import alloc as oal
+    n = 0
+    for c in GOLD["paged_cases"]:
+        if c["kind"] == "extend":
+            out, pages, toks = oal.alloc_extend(c["prefix_lens"], c["seq_lens"], c["last_loc"], c["free_pages"], c["page_size"])
+            assert toks == int((c["seq_lens"] - c["prefix_lens"]).sum())
+        else:
+            out, pages = oal.alloc_decode(c["seq_lens"], c["last_loc"], c["free_pages"], c["page_size"])
+        assert torch.equal(out, c["out_indices"]) and pages == c["num_new_pages"]
+        n += 1
+    assert n == 12
+    # the case the reference's torch form mishandles: an extension that stays inside the old partial page
+    out, pages, toks = oal.alloc_extend(torch.tensor([5]), torch.tensor([7]), torch.tensor([4 * 8 + 4]), torch.tensor([9]), 8)
+    assert out.tolist() == [37, 38] and pages == 0 and toks == 2
