@@ -1,9 +1,9 @@
 // Ragged extend (prefill-with-prefix) attention -- gfx950, wave64, MFMA 16x16x32.
 //
-// Workgroup = 4 waves = 64 query rows that share ONE kv head of ONE request:
-//   group >= 4 : 16 tokens x 4 q heads      (wave w -> q head 4*hg + w)
-//   group == 2 : 32 tokens x 2 q heads      group == 1 : 64 tokens x 1 q head
-// so every K/V tile staged in LDS is reused by 64 rows.  Keys are walked in tiles of 32:
+// Workgroup = 4 waves = 128 query rows (64 for short extends) that share ONE kv head of ONE request:
+//   group >= 4 : 32 tokens x 4 q heads      (wave w -> q head 4*hg + w, 32 tokens = two 16-row MFMA tiles)
+//   group == 2 : 64 tokens x 2 q heads      group == 1 : 128 tokens x 1 q head
+// so every K/V tile staged in LDS is reused by 128 rows.  Keys are walked in tiles of 64 (double-buffered):
 // first the cached prefix (gathered slot by slot through kv_indices from the paged pool),
 // then the new tokens (contiguous k_ext/v_ext), i.e. the new tokens never round-trip
 // through the pool.  Per tile and wave:
@@ -12,9 +12,11 @@
 //   O^T[d][row]   += V^T . P^T         A = V^T via ds_read_b64_tr_b16 (hardware transpose of the
 //                                      row-major V tile), B = P^T straight from the S^T registers
 // Global->LDS staging is register-staged and split (issue loads for tile t+1 before computing
-// tile t, write them after).  LDS rows are padded by 32 B: conflict-free for both read kinds.
+// tile t, write them into the other LDS stage after; one barrier per tile).  LDS rows are padded by 32 B:
+// conflict-free for both read kinds.
 // Bound: MFMA for long extends, HBM gather for long prefixes.
 #include "common.h"
+#include <stdlib.h>
 
 struct ExtendParams {
   const void* q;
@@ -35,23 +37,27 @@ struct ExtendParams {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <typename T, int D, int HG>  // HG q heads per workgroup (1, 2 or 4)
-__global__ __launch_bounds__(256) void extend_attn_kernel(const ExtendParams p) {
+// RT = 16-row MFMA tiles per wave (a wave owns 16*RT query rows of ONE q head), KH = 16-key halves per key
+// tile (tile = 16*KH keys).  <RT=2, KH=4>: 128 query rows per workgroup share every 64-key tile, each K / V^T
+// fragment read from LDS feeds two MFMAs, and the tile buffers are double-buffered: ONE barrier per 64 keys
+// (the first form, <1, 2> single-buffered, paid two barriers per 32 keys and reached 0.25-0.32 PFLOP/s).
+template <typename T, int D, int HG, int RT, int KH>  // HG q heads per workgroup (1, 2 or 4)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))   // <= 256 registers: two workgroups per CU
+void extend_attn_kernel(const ExtendParams p) {
   constexpr int KS = D / 32;
   constexpr int DB = D / 16;
   constexpr int ROW = D * 2 + 32;       // padded LDS row, bytes
-  constexpr int BQ = 64 / HG;           // tokens per workgroup
+  constexpr int KT = 16 * KH;           // keys per tile
+  constexpr int BQ = 64 * RT / HG;      // tokens per workgroup
   constexpr int TPR = 256 / (D / 8);    // key rows staged per pass by 256 threads (16 B each)
-  constexpr int NPASS = 32 / TPR;       // passes per 32-key tile (2 for D=128, 1 for D=64)
+  constexpr int STAGE = 2 * KT * ROW;   // K tile + V tile
   typedef typename Elem<T>::vec8 vec8;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ks_lds = smem;
-  char* vs_lds = smem + 32 * ROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g4 = lane >> 4, c16 = lane & 15;
-  const int qb = blockIdx.x;
+  const int qb = gridDim.x - 1 - blockIdx.x;   // causal: the blocks with the most keys are dispatched first (shorter tail)
   const int hgroups = p.group / HG;
   const int hk = blockIdx.y / hgroups;
   const int hg = blockIdx.y % hgroups;
@@ -64,167 +70,226 @@ __global__ __launch_bounds__(256) void extend_attn_kernel(const ExtendParams p) 
   if (qb * BQ >= ext_len) return;  // whole workgroup: no barrier reached yet
 
   const int head = hk * p.group + hg * HG + (wave % HG);
-  const int tok0 = qb * BQ + (wave / HG) * 16;  // first token (within the extend) of this wave
-  const int my_tok = min(tok0 + c16, ext_len - 1);
+  const int tok0 = qb * BQ + (wave / HG) * (16 * RT);  // first token (within the extend) of this wave
   const bool wave_active = tok0 < ext_len;
 
-  // ---- Q fragments (B operand): lane -> row c16, dims 32*ks + 8*g4
-  vec8 qf[KS];
-  {
+  // ---- Q fragments (B operand): lane -> row c16 of row tile rt, dims 32*ks + 8*g4
+  vec8 qf[RT][KS];
+  int32_t q_pos[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int my_tok = min(tok0 + 16 * rt + c16, ext_len - 1);
+    q_pos[rt] = prefix + my_tok;     // absolute position of this lane's query row
     const T* qp = (const T*)p.q + (int64_t)(q_start + my_tok) * p.stride_q_tok + (int64_t)head * D + g4 * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(vec8, *(const uint4*)(qp + ks * 32));
+    for (int ks = 0; ks < KS; ++ks) qf[rt][ks] = __builtin_bit_cast(vec8, *(const uint4*)(qp + ks * 32));
   }
 
   // keys this workgroup needs: prefix + (causal ? tokens up to the block's last : all)
   const int32_t blk_last = min(ext_len, (qb + 1) * BQ);
   const int32_t n_keys = prefix + (p.causal ? blk_last : ext_len);
-  const int32_t n_tiles = (n_keys + 31) / 32;
+  const int32_t n_tiles = (n_keys + KT - 1) / KT;
 
-  // ---- staging: thread -> (row srow + TPR*pass, 16-byte chunk schunk)
+  // ---- staging: thread -> (row srow + TPR*pass, 16-byte chunk schunk); registers between global and LDS
   const int srow = tid / (D / 8), schunk = tid % (D / 8);
-  // named registers + macros (arrays captured by lambdas / indexed in loops ended up in scratch)
+  // The next tile is staged in NSUB pieces of 32 keys, each loaded before and written after one 32-key
+  // sub-tile of compute (the other LDS stage is free for the whole iteration), so only 32 keys' worth of
+  // staging registers is live.  Named registers + macros: register ARRAYS here ended up in scratch.
+  constexpr int NSUB = KH / 2;          // 32-key sub-tiles per LDS tile
+  constexpr int SPASS = 32 / TPR;       // staging passes per sub-tile (2 for D=128, 1 for D=64)
+  static_assert(SPASS == 1 || SPASS == 2, "staging passes");
   uint4 kreg0, vreg0, kreg1, vreg1;
-#define STAGE_LOAD_ONE(tile_, ps_, KR, VR)                                                    \
-  {                                                                                           \
-    int32_t kp_ = (tile_) * 32 + srow + TPR * (ps_);                                          \
-    kp_ = min(kp_, n_keys - 1);                                                               \
-    const bool in_pool_ = kp_ < prefix;                                                       \
-    const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + min(kp_, max(prefix - 1, 0))] : 0; \
-    const int64_t t_ = q_start + max(kp_ - prefix, 0);                                        \
+#define STAGE_LOAD_ONE(tile_, sub_, ps_, KR, VR)                                                                \
+  {                                                                                                             \
+    int32_t kp_ = (tile_) * KT + (sub_) * 32 + srow + TPR * (ps_);                                              \
+    kp_ = min(kp_, n_keys - 1);                                                                                 \
+    const bool in_pool_ = kp_ < prefix;                                                                         \
+    const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + min(kp_, max(prefix - 1, 0))] : 0;        \
+    const int64_t t_ = q_start + max(kp_ - prefix, 0);                                                          \
     const T* kr_ = in_pool_ ? (const T*)p.k_buf + slot_ * p.stride_k_slot : (const T*)p.k_ext + t_ * p.stride_kx_tok; \
     const T* vr_ = in_pool_ ? (const T*)p.v_buf + slot_ * p.stride_v_slot : (const T*)p.v_ext + t_ * p.stride_vx_tok; \
-    KR = *(const uint4*)(kr_ + (int64_t)hk * D + schunk * 8);                                 \
-    VR = *(const uint4*)(vr_ + (int64_t)hk * D + schunk * 8);                                 \
+    KR = *(const uint4*)(kr_ + (int64_t)hk * D + schunk * 8);                                                   \
+    VR = *(const uint4*)(vr_ + (int64_t)hk * D + schunk * 8);                                                   \
   }
-#define STAGE_LOAD(tile_)                                       \
-  {                                                             \
-    STAGE_LOAD_ONE(tile_, 0, kreg0, vreg0);                     \
-    if constexpr (NPASS == 2) STAGE_LOAD_ONE(tile_, 1, kreg1, vreg1); \
+#define STAGE_LOAD(tile_, sub_)                                                  \
+  {                                                                              \
+    STAGE_LOAD_ONE(tile_, sub_, 0, kreg0, vreg0);                                \
+    if constexpr (SPASS == 2) STAGE_LOAD_ONE(tile_, sub_, 1, kreg1, vreg1);      \
   }
-#define STAGE_WRITE()                                                         \
-  {                                                                           \
-    *(uint4*)(ks_lds + srow * ROW + schunk * 16) = kreg0;                     \
-    *(uint4*)(vs_lds + srow * ROW + schunk * 16) = vreg0;                     \
-    if constexpr (NPASS == 2) {                                               \
-      *(uint4*)(ks_lds + (srow + TPR) * ROW + schunk * 16) = kreg1;           \
-      *(uint4*)(vs_lds + (srow + TPR) * ROW + schunk * 16) = vreg1;           \
-    }                                                                         \
+#define STAGE_WRITE(st_, sub_)                                                               \
+  {                                                                                          \
+    char* ksw_ = smem + (st_) * STAGE + ((sub_) * 32 + srow) * ROW + schunk * 16;            \
+    char* vsw_ = ksw_ + KT * ROW;                                                            \
+    *(uint4*)ksw_ = kreg0;                                                                   \
+    *(uint4*)vsw_ = vreg0;                                                                   \
+    if constexpr (SPASS == 2) {                                                              \
+      *(uint4*)(ksw_ + TPR * ROW) = kreg1;                                                   \
+      *(uint4*)(vsw_ + TPR * ROW) = vreg1;                                                   \
+    }                                                                                        \
   }
 
-  f32x4 acc[DB];
+  f32x4 acc[RT][DB];
+  float m[RT], lsum[RT];
 #pragma unroll
-  for (int db = 0; db < DB; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, lsum = 0.f;
-  const int32_t q_pos = prefix + my_tok;  // absolute position of this lane's query row
-  // last key (exclusive) this WAVE can see: lets early waves skip fully masked tiles
-  const int32_t wave_keys = p.causal ? prefix + min(ext_len, tok0 + 16) : n_keys;
+  for (int rt = 0; rt < RT; ++rt) {
+    m[rt] = -INFINITY;
+    lsum[rt] = 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) acc[rt][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // last key (exclusive) this WAVE can see: lets early waves skip fully masked sub-tiles
+  const int32_t wave_keys = p.causal ? prefix + min(ext_len, tok0 + 16 * RT) : n_keys;
 
-  STAGE_LOAD(0);
-  STAGE_WRITE();
+#pragma unroll
+  for (int sub = 0; sub < NSUB; ++sub) {
+    STAGE_LOAD(0, sub);
+    STAGE_WRITE(0, sub);
+  }
   __syncthreads();
 
   for (int32_t tile = 0; tile < n_tiles; ++tile) {
+    const int st = tile & 1;
     const bool has_next = tile + 1 < n_tiles;
-    if (has_next) STAGE_LOAD(tile + 1);
-
-    if (wave_active && tile * 32 < wave_keys) {
-      // ---- S^T = K . Q^T for the two 16-key halves
-      f32x4 s[2];
+    const char* ks_lds = smem + st * STAGE;
+    const char* vs_lds = ks_lds + KT * ROW;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        s[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* kr = ks_lds + (16 * h + c16) * ROW + g4 * 16;
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (has_next) STAGE_LOAD(tile + 1, sub);
+      const int32_t kbase = tile * KT + sub * 32;
+      if (wave_active && kbase < wave_keys) {
+        // every key of the sub-tile visible to every row of the wave?  (then no mask arithmetic at all)
+        const bool all_visible = kbase + 31 < n_keys && (!p.causal || kbase + 31 <= prefix + tok0) && p.sliding_window <= 0;
+        // ---- S^T = K . Q^T for the two 16-key halves of the sub-tile; each K fragment feeds the RT row tiles
+        f32x4 s[RT][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const vec8 kf = __builtin_bit_cast(vec8, *(const uint4*)(kr + ks * 64));
-          s[h] = Elem<T>::mfma16(kf, qf[ks], s[h]);
-        }
-      }
-      // ---- scale, cap, mask
-      float sc[2][4];
-      float tm = -INFINITY;
+        for (int rt = 0; rt < RT; ++rt) s[rt][0] = s[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+          const char* kr = ks_lds + (32 * sub + 16 * h + c16) * ROW + g4 * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x;
-          if (p.logit_cap > 0.f) {
-            const float y = s[h][r] * p.sm_scale / p.logit_cap;
-            const float e = __expf(2.f * y);
-            x = p.logit_cap * (1.f - 2.f / (e + 1.f)) * 1.4426950408889634f;
-          } else {
-            x = s[h][r] * p.scale_log2;
+          for (int ks = 0; ks < KS; ++ks) {
+            const vec8 kf = __builtin_bit_cast(vec8, *(const uint4*)(kr + ks * 64));
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) s[rt][h] = Elem<T>::mfma16(kf, qf[rt][ks], s[rt][h]);
           }
-          const int32_t kp = tile * 32 + 16 * h + 4 * g4 + r;
-          bool ok = kp < n_keys;
-          if (p.causal) ok = ok && (kp <= q_pos);
-          if (p.sliding_window > 0) ok = ok && ((int64_t)q_pos <= (int64_t)kp + p.sliding_window);
-          x = ok ? x : -INFINITY;
-          sc[h][r] = x;
-          tm = fmaxf(tm, x);
         }
-      tm = fmaxf(tm, __shfl_xor(tm, 16));
-      tm = fmaxf(tm, __shfl_xor(tm, 32));
-      const float mn = fmaxf(m, tm);
-      const float msafe = (mn == -INFINITY) ? 0.f : mn;
-      const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - msafe);
-      m = mn;
-      float pr[2][4], psum = 0.f;
+        // ---- scale, cap, mask, online softmax; P^T packed as the B operand of the PV MFMAs:
+        // k-slot (g4, j): j<4 -> key 4*g4+j of the first half, j>=4 -> of the second
+        vec8 pf[RT];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int rt = 0; rt < RT; ++rt) {
+          float sc[2][4];
+          float tm = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[h][r] = fast_exp2(sc[h][r] - msafe);
-          psum += pr[h][r];
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x;
+              if (p.logit_cap > 0.f) {
+                const float y = s[rt][h][r] * p.sm_scale / p.logit_cap;
+                const float e = __expf(2.f * y);
+                x = p.logit_cap * (1.f - 2.f / (e + 1.f)) * 1.4426950408889634f;
+              } else {
+                x = s[rt][h][r] * p.scale_log2;
+              }
+              if (!all_visible) {   // wave-uniform: only diagonal / last / windowed sub-tiles pay for the mask
+                const int32_t kp = kbase + 16 * h + 4 * g4 + r;
+                bool ok = kp < n_keys;
+                if (p.causal) ok = ok && (kp <= q_pos[rt]);
+                if (p.sliding_window > 0) ok = ok && ((int64_t)q_pos[rt] <= (int64_t)kp + p.sliding_window);
+                x = ok ? x : -INFINITY;
+              }
+              sc[h][r] = x;
+              tm = fmaxf(tm, x);
+            }
+          tm = fmaxf(tm, __shfl_xor(tm, 16));
+          tm = fmaxf(tm, __shfl_xor(tm, 32));
+          // deferred rescale: the running max only moves when it grows by more than 2^8 (P <= 2^8 is exact enough
+          // in fp32 / the MFMA input type; the final 1/lsum normalisation uses the same reference max)
+          if (__any(tm > m[rt] + 8.0f)) {
+            const float mn = fmaxf(m[rt], tm);
+            const float mns = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = (m[rt] == -INFINITY) ? 0.f : fast_exp2(m[rt] - mns);
+            m[rt] = mn;
+            lsum[rt] *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) acc[rt][db] *= alpha;
+          }
+          const float msafe = (m[rt] == -INFINITY) ? 0.f : m[rt];
+          float pr[2][4], psum = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pr[h][r] = fast_exp2(sc[h][r] - msafe);
+              psum += pr[h][r];
+            }
+          lsum[rt] += psum;
+          const u32x4 pw = {pack2<T>(pr[0][0], pr[0][1]), pack2<T>(pr[0][2], pr[0][3]),
+                            pack2<T>(pr[1][0], pr[1][1]), pack2<T>(pr[1][2], pr[1][3])};
+          pf[rt] = __builtin_bit_cast(vec8, pw);
         }
-      lsum = lsum * alpha + psum;
+        // ---- O^T += V^T . P^T ; V^T fragments by transposed LDS reads, each feeds the RT row tiles
+        const int qq = c16 >> 2, pp = c16 & 3;
+        const char* vr0 = vs_lds + (32 * sub + 4 * g4 + qq) * ROW + pp * 8;
 #pragma unroll
-      for (int db = 0; db < DB; ++db) acc[db] *= alpha;
-      // ---- P^T as the B operand: k-slot (g4, j): j<4 -> key 4*g4+j, j>=4 -> key 16+4*g4+(j-4)
-      const u32x4 pw = {pack2<T>(pr[0][0], pr[0][1]), pack2<T>(pr[0][2], pr[0][3]),
-                        pack2<T>(pr[1][0], pr[1][1]), pack2<T>(pr[1][2], pr[1][3])};
-      const vec8 pf = __builtin_bit_cast(vec8, pw);
-      // ---- O^T += V^T . P^T ; V^T fragments by transposed LDS reads
-      const int qq = c16 >> 2, pp = c16 & 3;
-      const char* vr0 = vs_lds + (4 * g4 + qq) * ROW + pp * 8;
+        for (int db = 0; db < DB; ++db) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr0 + db * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr0 + 16 * ROW + db * 32));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr0 + db * 32));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr0 + 16 * ROW + db * 32));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[db] = Elem<T>::mfma16(__builtin_bit_cast(vec8, both), pf, acc[db]);
+          for (int rt = 0; rt < RT; ++rt) acc[rt][db] = Elem<T>::mfma16(__builtin_bit_cast(vec8, both), pf[rt], acc[rt][db]);
+        }
       }
+      // the other stage was last read in the previous iteration (every wave is past that iteration's barrier)
+      if (has_next) STAGE_WRITE(st ^ 1, sub);
     }
-    __syncthreads();  // everyone is done reading this tile
-    if (has_next) {
-      STAGE_WRITE();
-      __syncthreads();
-    }
+    __syncthreads();
   }
 
   // ---- epilogue: lane holds O[row c16][d = 16*db + 4*g4 + r]
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
-  if (wave_active && tok0 + c16 < ext_len) {
-    const float inv = 1.f / lsum;
-    T* op = (T*)p.o + (int64_t)(q_start + tok0 + c16) * p.stride_o_tok + (int64_t)head * D + 4 * g4;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      *(uint2*)(op + db * 16) = make_uint2(pack2<T>(acc[db][0] * inv, acc[db][1] * inv),
-                                           pack2<T>(acc[db][2] * inv, acc[db][3] * inv));
+  for (int rt = 0; rt < RT; ++rt) {
+    float l = lsum[rt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (wave_active && tok0 + 16 * rt + c16 < ext_len) {
+      const float inv = 1.f / l;
+      T* op = (T*)p.o + (int64_t)(q_start + tok0 + 16 * rt + c16) * p.stride_o_tok + (int64_t)head * D + 4 * g4;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        *(uint2*)(op + db * 16) = make_uint2(pack2<T>(acc[rt][db][0] * inv, acc[rt][db][1] * inv),
+                                             pack2<T>(acc[rt][db][2] * inv, acc[rt][db][3] * inv));
+      }
     }
   }
 }
 
+#undef STAGE_LOAD
+#undef STAGE_WRITE
+#undef STAGE_LOAD_ONE
+
+static int extend_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 template <typename T, int D, int HG>
 static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
-  constexpr int BQ = 64 / HG;
   constexpr int ROW = D * 2 + 32;
-  const size_t lds = 2 * 32 * ROW;
-  dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
-  extend_attn_kernel<T, D, HG><<<grid, 256, lds, st>>>(p);
+  // measured (8 x 2048 causal, Llama-3-8B heads): <1,2> 0.656 ms (419 TFLOP/s, 112 VGPRs: 4 workgroups per CU),
+  // <2,4> 0.873 ms (209 VGPRs: 2 per CU) -- occupancy beats fragment reuse here; the big form stays selectable
+  static const int big = extend_env("MI_EXTEND_BIG", 0);
+  if (big && max_extend_len > 16) {       // 128 rows x 64-key tiles, double-buffered
+    constexpr int BQ = 128 / HG;
+    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
+    extend_attn_kernel<T, D, HG, 2, 4><<<grid, 256, 2 * 2 * 64 * ROW, st>>>(p);
+  } else {                                // short extends (speculative verify, chunk tails): 64 rows x 32-key tiles
+    constexpr int BQ = 64 / HG;
+    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
+    extend_attn_kernel<T, D, HG, 1, 2><<<grid, 256, 2 * 2 * 32 * ROW, st>>>(p);
+  }
 }
 
 template <typename T, int D>
