@@ -178,7 +178,7 @@ def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, reps=2):
                       f"flops = linears {lin:.3e} + causal attention {attn:.3e} + lm_head {head:.3e}"}
 
 
-def cpu_baseline(shape, B, S, sample_requests=32, timed_layers=2):
+def cpu_baseline(shape, B, S, sample_requests=64, timed_layers=12):
     """The reference's torch-native arithmetic (our CPU restatement, oracle/) for ONE decoder layer,
     timed on the host cores on a bounded sample: linears / norm / rope / activation at the full batch
     B, attention on `sample_requests` of the B requests at the full KV length S (its per-request loop

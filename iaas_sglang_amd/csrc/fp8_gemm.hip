@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) void fp8_gemm_skinny_kernel(const GemmPara
   // j so that at any instant the chip touches many different weight/activation columns
   const int64_t KF = K / 128;
   const int64_t J = (KF > wave) ? (KF - wave + NW - 1) / NW : 0;
-  const int64_t rot = p.rotate ? (int64_t)(blockIdx.x % (unsigned)(J > 0 ? J : 1)) : 0;
+  const int64_t rot = (p.rotate & 1) ? (int64_t)(blockIdx.x % (unsigned)(J > 0 ? J : 1)) : 0;
 
   // Two register buffers (a/b) as plain arrays + macros: no structs/lambdas, so nothing can end up
   // in scratch.  Loads never sit under a condition (a per-load select makes hipcc branch and drain
@@ -572,8 +572,12 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
   }
 }
 
-static int gemm_rotate() {
-  static const int r = [] { const char* e = getenv("MI_GEMM_ROTATE"); return e ? atoi(e) : 1; }();
+static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8+: tile-kernel group size override (tuning)
+  static const int r = [] {
+    const char* e = getenv("MI_GEMM_ROTATE");
+    const char* g = getenv("MI_GEMM_TILE_GROUP_M");
+    return (e ? atoi(e) : 1) | ((g ? atoi(g) : 0) << 8);
+  }();
   return r;
 }
 static int xs_env(const char* name, int dflt) {
@@ -637,9 +641,13 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
 //     A operand, activations as B (each lane ends with 4 consecutive n of one output row);
 //   * v_mfma_scale_f32_16x16x128_f8f6f4, unit scales: one MFMA per (m-tile, n-tile, k-step);
 //   * one DMA-wait + barrier per k-step (stage k+1 is issued before computing k);
-//   * blocks are renumbered so that the 8 XCDs each walk a contiguous range of tiles with m fastest:
-//     the tiles resident on one XCD at a time share their weight rows in that XCD's L2.
-// Bound: MFMA (2*M*N*K flops); tile traffic 64 KiB per 16.8 MFLOP keeps L2 at ~32 B/clk/CU.
+//   * blocks are renumbered so that the 8 XCDs each walk a contiguous range of tiles, in groups of
+//     8 m-blocks x all n: the ~32 tiles resident on one XCD form an 8 x 4 patch and share BOTH operands
+//     in that XCD's L2 (TCC hit rate 76-81 % vs 49-72 % with m fastest over all of M).
+// Bound (measured, gate_up shape 16384 x 28672 x 4096: 2.27 ms = 1.70 PFLOP/s): the stage-ahead DMA.  With the
+// MFMAs removed the kernel still takes 1.94 ms: one 64-KiB stage per CU takes ~2.2 us to land under full
+// load (L2 hits + 24 % from the Infinity Cache), the MMA of a k-step ~0.85 us, and 160 KiB of LDS hold only
+// two 64-KiB stages -- one stage in flight.  Next: finer ring units (quarter stages) or a 4-wave x 2 form.
 template <typename OutT>
 __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks) {
   constexpr int BM = 256, BN = 256, BK = 128;
@@ -655,7 +663,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const int orig = blockIdx.x;
   const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
   const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-  const int nb = tid / mblocks, mb = tid % mblocks;
+  // grouped order inside an XCD's range: the ~32 tiles resident on an XCD at one time form a GM x (32/GM)
+  // patch (8 m-blocks x 4 n-blocks), so BOTH operands are shared in that XCD's L2 (12 operand blocks per 32
+  // tiles instead of 33 with m fastest over all of M: the activations were re-read from HBM/MALL once per
+  // n-block -- 7.5 GB per gate_up GEMM, which is what bounded the kernel)
+  const int GM = p.rotate >> 8 ? p.rotate >> 8 : 8;
+  const int per_group = GM * nblocks;
+  const int grp = tid / per_group, in_grp = tid % per_group;
+  const int first_m = grp * GM;
+  const int gsz = min(mblocks - first_m, GM);
+  const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
   const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * BN;
   const int64_t KT = p.K / BK;
 
