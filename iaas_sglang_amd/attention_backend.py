@@ -213,20 +213,21 @@ class MiAttnBackend(AttentionBackend):
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
-        if k_buf.element_size() == 1:
-            # fp8 pool: the new tokens are attended from the k/v ARGUMENTS (and were just written to the pool in
-            # fp8); only a cached prefix would be read back from the pool, and the extend kernel has no fp8
-            # staging path yet -> prefill without prefix works, prefix reuse does not
-            pre = forward_batch.extend_prefix_lens_cpu
-            if pre is None or sum(int(x) for x in pre) > 0:
-                raise NotImplementedError("MiAttnBackend: extend over a cached PREFIX in an fp8 KV pool is not wired "
-                                          "(prefill without prefix and decode are)")
-            k_buf = k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim)     # never dereferenced: no prefix keys
-            v_buf = v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim)
         causal = not (getattr(layer, "is_cross_attention", False)
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
         window = getattr(layer, "sliding_window_size", -1)
         window = -1 if window is None else int(window)
+        if k_buf.element_size() == 1:
+            # fp8 pool: the cached prefix is read (and converted) from the pool; the new tokens are attended from
+            # the T-typed k/v arguments, exactly as in the bf16 case (they were just written to the pool in fp8)
+            ks, vs = self._kv_scales(layer)
+            ops.extend_attention_fp8kv(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                                       k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                                       v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
+                                       o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, ks, vs,
+                                       md.qo_indptr, md.kv_indptr, md.kv_indices, md.max_extend_len, layer.scaling,
+                                       getattr(layer, "logit_cap", 0.0) or 0.0, causal, window if window > 0 else -1)
+            return o
         ops.extend_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
                              k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
                              v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),

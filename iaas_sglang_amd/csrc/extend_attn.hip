@@ -32,16 +32,28 @@ struct ExtendParams {
   int64_t stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok, stride_k_slot, stride_v_slot;
   int64_t sliding_window;
   float scale_log2, sm_scale, logit_cap;
+  float k_scale, v_scale;   // fp8 pool (KV8): prefix keys are k8 * k_scale, prefix values v8 * v_scale
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// 8 fp8 e4m3fn bytes -> 8 T elements (exact: every e4m3 value is a bf16 / fp16 value)
+typedef __attribute__((ext_vector_type(2))) float ext_f32x2;
+template <typename T> __device__ __forceinline__ uint4 fp8x8_to_T(uint2 u) {
+  const ext_f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, true);
+  const ext_f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, true);
+  return make_uint4(pack2<T>(a[0], a[1]), pack2<T>(b[0], b[1]), pack2<T>(c[0], c[1]), pack2<T>(d[0], d[1]));
+}
+
 // RT = 16-row MFMA tiles per wave (a wave owns 16*RT query rows of ONE q head), KH = 16-key halves per key
 // tile (tile = 16*KH keys).  <RT=2, KH=4>: 128 query rows per workgroup share every 64-key tile, each K / V^T
 // fragment read from LDS feeds two MFMAs, and the tile buffers are double-buffered: ONE barrier per 64 keys
 // (the first form, <1, 2> single-buffered, paid two barriers per 32 keys and reached 0.25-0.32 PFLOP/s).
-template <typename T, int D, int HG, int RT, int KH>  // HG q heads per workgroup (1, 2 or 4)
+// KV8: the POOL (cached prefix) holds fp8 e4m3fn rows (strides in bytes); they are converted to T while being
+// staged (exact), k_scale multiplies the prefix logits and v_scale the prefix probabilities fed to the PV MFMA
+// (never the softmax denominator).  The new tokens (k_ext / v_ext) stay T-typed and unscaled.
+template <typename T, int D, int HG, int RT, int KH, bool KV8>  // HG q heads per workgroup (1, 2 or 4)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))   // <= 256 registers: two workgroups per CU
 void extend_attn_kernel(const ExtendParams p) {
   constexpr int KS = D / 32;
@@ -106,10 +118,17 @@ void extend_attn_kernel(const ExtendParams p) {
     const bool in_pool_ = kp_ < prefix;                                                                         \
     const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + min(kp_, max(prefix - 1, 0))] : 0;        \
     const int64_t t_ = q_start + max(kp_ - prefix, 0);                                                          \
-    const T* kr_ = in_pool_ ? (const T*)p.k_buf + slot_ * p.stride_k_slot : (const T*)p.k_ext + t_ * p.stride_kx_tok; \
-    const T* vr_ = in_pool_ ? (const T*)p.v_buf + slot_ * p.stride_v_slot : (const T*)p.v_ext + t_ * p.stride_vx_tok; \
-    KR = *(const uint4*)(kr_ + (int64_t)hk * D + schunk * 8);                                                   \
-    VR = *(const uint4*)(vr_ + (int64_t)hk * D + schunk * 8);                                                   \
+    if (KV8 && in_pool_) {                                                                                      \
+      const uint2 k8_ = *(const uint2*)((const uint8_t*)p.k_buf + slot_ * p.stride_k_slot + (int64_t)hk * D + schunk * 8); \
+      const uint2 v8_ = *(const uint2*)((const uint8_t*)p.v_buf + slot_ * p.stride_v_slot + (int64_t)hk * D + schunk * 8); \
+      KR = fp8x8_to_T<T>(k8_);                                                                                  \
+      VR = fp8x8_to_T<T>(v8_);                                                                                  \
+    } else {                                                                                                    \
+      const T* kr_ = (!KV8 && in_pool_) ? (const T*)p.k_buf + slot_ * p.stride_k_slot : (const T*)p.k_ext + t_ * p.stride_kx_tok; \
+      const T* vr_ = (!KV8 && in_pool_) ? (const T*)p.v_buf + slot_ * p.stride_v_slot : (const T*)p.v_ext + t_ * p.stride_vx_tok; \
+      KR = *(const uint4*)(kr_ + (int64_t)hk * D + schunk * 8);                                                 \
+      VR = *(const uint4*)(vr_ + (int64_t)hk * D + schunk * 8);                                                 \
+    }                                                                                                           \
   }
 #define STAGE_LOAD(tile_, sub_)                                                  \
   {                                                                              \
@@ -192,6 +211,16 @@ void extend_attn_kernel(const ExtendParams p) {
               } else {
                 x = s[rt][h][r] * p.scale_log2;
               }
+              if constexpr (KV8) {   // prefix keys come from the fp8 pool: logits * k_scale (cap path: before the cap)
+                if (p.logit_cap > 0.f) {
+                  const float sk = (kbase + 16 * h + 4 * g4 + r < prefix) ? p.k_scale : 1.f;
+                  const float y = s[rt][h][r] * sk * p.sm_scale / p.logit_cap;
+                  const float e = __expf(2.f * y);
+                  x = p.logit_cap * (1.f - 2.f / (e + 1.f)) * 1.4426950408889634f;
+                } else if (kbase + 16 * h + 4 * g4 + r < prefix) {
+                  x *= p.k_scale;
+                }
+              }
               if (!all_visible) {   // wave-uniform: only diagonal / last / windowed sub-tiles pay for the mask
                 const int32_t kp = kbase + 16 * h + 4 * g4 + r;
                 bool ok = kp < n_keys;
@@ -225,6 +254,15 @@ void extend_attn_kernel(const ExtendParams p) {
               psum += pr[h][r];
             }
           lsum[rt] += psum;
+          if constexpr (KV8) {   // prefix values are v8 * v_scale: scale their probabilities for the PV MFMA only
+            if (kbase < prefix) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (kbase + 16 * h + 4 * g4 + r < prefix) pr[h][r] *= p.v_scale;
+            }
+          }
           const u32x4 pw = {pack2<T>(pr[0][0], pr[0][1]), pack2<T>(pr[0][2], pr[0][3]),
                             pack2<T>(pr[1][0], pr[1][1]), pack2<T>(pr[1][2], pr[1][3])};
           pf[rt] = __builtin_bit_cast(vec8, pw);
@@ -275,7 +313,7 @@ static int extend_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int D, int HG>
+template <typename T, int D, int HG, bool KV8>
 static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
   constexpr int ROW = D * 2 + 32;
   // measured (8 x 2048 causal, Llama-3-8B heads): <1,2> 0.656 ms (419 TFLOP/s, 112 VGPRs: 4 workgroups per CU),
@@ -284,31 +322,31 @@ static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_exte
   if (big && max_extend_len > 16) {       // 128 rows x 64-key tiles, double-buffered
     constexpr int BQ = 128 / HG;
     dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
-    extend_attn_kernel<T, D, HG, 2, 4><<<grid, 256, 2 * 2 * 64 * ROW, st>>>(p);
+    extend_attn_kernel<T, D, HG, 2, 4, KV8><<<grid, 256, 2 * 2 * 64 * ROW, st>>>(p);
   } else {                                // short extends (speculative verify, chunk tails): 64 rows x 32-key tiles
     constexpr int BQ = 64 / HG;
     dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
-    extend_attn_kernel<T, D, HG, 1, 2><<<grid, 256, 2 * 2 * 32 * ROW, st>>>(p);
+    extend_attn_kernel<T, D, HG, 1, 2, KV8><<<grid, 256, 2 * 2 * 32 * ROW, st>>>(p);
   }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool KV8 = false>
 static int launch_extend_g(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
   const int g = p.group;
-  if (g % 4 == 0) launch_extend<T, D, 4>(p, batch, max_extend_len, st);
-  else if (g % 2 == 0) launch_extend<T, D, 2>(p, batch, max_extend_len, st);
-  else launch_extend<T, D, 1>(p, batch, max_extend_len, st);
+  if (g % 4 == 0) launch_extend<T, D, 4, KV8>(p, batch, max_extend_len, st);
+  else if (g % 2 == 0) launch_extend<T, D, 2, KV8>(p, batch, max_extend_len, st);
+  else launch_extend<T, D, 1, KV8>(p, batch, max_extend_len, st);
   return MI_OK;
 }
 
-extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
-                              const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
-                              const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
-                              int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
-                              int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
-                              int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
-                              int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
-                              int64_t sliding_window, int dtype, void* stream) {
+static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                            const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                            const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
+                            int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                            int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                            int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                            int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                            int64_t sliding_window, int dtype, void* stream, bool kv8, float k_scale, float v_scale) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
   MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
@@ -330,8 +368,14 @@ extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* 
   p.stride_vx_tok = stride_vx_tok; p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
   p.sliding_window = sliding_window; p.sm_scale = sm_scale; p.logit_cap = logit_cap;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.k_scale = k_scale; p.v_scale = v_scale;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MI_BF16) {
+  if (kv8) {
+    MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
+    if (head_dim != 128) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_extend_attn_fp8kv: head_dim 128 only");
+    if (dtype == MI_BF16) launch_extend_g<bf16_t, 128, true>(p, batch, max_extend_len, st);
+    else launch_extend_g<f16_t, 128, true>(p, batch, max_extend_len, st);
+  } else if (dtype == MI_BF16) {
     if (head_dim == 128) launch_extend_g<bf16_t, 128>(p, batch, max_extend_len, st);
     else launch_extend_g<bf16_t, 64>(p, batch, max_extend_len, st);
   } else {
@@ -340,4 +384,31 @@ extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* 
   }
   MI_CHECK_LAUNCH();
   return MI_OK;
+}
+
+extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                              const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                              const int32_t* kv_indptr, const int32_t* kv_indices, int64_t batch,
+                              int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                              int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                              int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                              int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                              int64_t sliding_window, int dtype, void* stream) {
+  return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, max_extend_len,
+                          num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
+                          stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype, stream, false,
+                          1.f, 1.f);
+}
+
+extern "C" int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                                    const void* k_buf8, const void* v_buf8, float k_scale, float v_scale,
+                                    const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                    int64_t batch, int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                                    int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_kx_tok,
+                                    int64_t stride_vx_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                                    float logit_cap, int causal, int64_t sliding_window, int dtype, void* stream) {
+  return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf8, v_buf8, qo_indptr, kv_indptr, kv_indices, batch, max_extend_len,
+                          num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
+                          stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype, stream, true,
+                          k_scale, v_scale);
 }

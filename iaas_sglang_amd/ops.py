@@ -170,6 +170,29 @@ def extend_attention(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, 
     return o
 
 
+def extend_attention_fp8kv(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
+                           k_buf8: torch.Tensor, v_buf8: torch.Tensor, k_scale: float, v_scale: float,
+                           qo_indptr: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,
+                           max_extend_len: int, sm_scale: float, logit_cap: float = 0.0, causal: bool = True,
+                           sliding_window: int = -1) -> torch.Tensor:
+    """extend_attention with the cached prefix in an fp8 (e4m3fn / uint8 storage) pool [slots, Hkv, 128]."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, o, k_ext, v_ext):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    for t in (k_buf8, v_buf8):
+        assert t.element_size() == 1 and t.stride(2) == 1 and t.stride(1) == D and t.shape[2] == D
+    assert qo_indptr.dtype == torch.int32 and kv_indptr_t.dtype == torch.int32 and kv_indices_t.dtype == torch.int32
+    check(lib.mi_extend_attn_fp8kv(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o), _ptr(k_buf8), _ptr(v_buf8), float(k_scale),
+                                   float(v_scale), _ptr(qo_indptr), _ptr(kv_indptr_t), _ptr(kv_indices_t), B,
+                                   int(max_extend_len), Hq, Hkv, D, q.stride(0), o.stride(0), k_ext.stride(0),
+                                   v_ext.stride(0), k_buf8.stride(0), v_buf8.stride(0), float(sm_scale),
+                                   float(logit_cap), int(causal), int(sliding_window), _dt(q), _stream()),
+          "mi_extend_attn_fp8kv")
+    return o
+
+
 def merge_state(o_a, lse_a, o_b, lse_b, out=None, out_lse=None) -> Tuple[torch.Tensor, torch.Tensor]:
     n, h, d = o_a.shape
     assert o_a.is_contiguous() and o_b.is_contiguous() and lse_a.is_contiguous() and lse_b.is_contiguous()

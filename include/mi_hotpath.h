@@ -150,6 +150,18 @@ int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void
                    int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                    int64_t sliding_window, int dtype, void* stream);
 
+/* mi_extend_attn whose cached PREFIX lives in an fp8 (e4m3fn) pool: k_buf8/v_buf8 hold bytes, stride_*_slot in
+ * BYTES, head_dim 128; prefix keys are k8 * k_scale, prefix values v8 * v_scale (converted while being staged);
+ * the new tokens k_ext/v_ext stay T-typed.  replaces: extend_attention_fwd over an fp8 MHATokenToKVPool. */
+int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                         const void* k_buf8, const void* v_buf8, float k_scale, float v_scale,
+                         const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                         int64_t batch, int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                         int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                         int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                         int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                         int64_t sliding_window, int dtype, void* stream);
+
 /* out = (a*e^{la} + b*e^{lb}) / (e^{la}+e^{lb}); out_lse = log(e^{la}+e^{lb})  (lse fp32, may be null)
  *   a,b,out [n,h,d] contiguous; lse [n,h].
  * replaces: merge_state_v2, sgl-kernel/csrc/attention/merge_attn_states.cu:31-106,182-204. */

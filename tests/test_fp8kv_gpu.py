@@ -80,8 +80,8 @@ def test_decode_attention_fp8kv_vs_oracle(Hq, Hkv, lens, splits, dtype, k_scale,
 
 
 def test_backend_with_fp8_pool_decode_and_prefill():
-    """MiAttnBackend over an fp8 MHATokenToKVPool: prefill (no prefix) writes fp8 rows and attends the bf16
-    arguments; decode steps read the fp8 pool; a cached prefix in extend is refused loudly."""
+    """MiAttnBackend over an fp8 MHATokenToKVPool: prefill writes fp8 rows and attends the bf16 arguments; decode
+    steps read the fp8 pool; an extend over a cached prefix reads (and converts) the prefix from the fp8 pool."""
     from iaas_sglang_amd import harness as H
     from iaas_sglang_amd.attention_backend import MiAttnBackend
     from iaas_sglang_amd.mem_cache import MHATokenToKVPool, ReqToTokenPool
@@ -132,11 +132,85 @@ def test_backend_with_fp8_pool_decode_and_prefill():
     refd = oa.decode_fp32_fp8kv(qd.view(3, Hq, D), k8, v8, runner.req_to_token_pool.req_to_token.cpu(),
                                 fb.req_pool_indices.cpu(), fb.seq_lens.cpu(), D ** -0.5, 0.5, 2.0)
     torch.testing.assert_close(od.view(3, Hq, D).cpu().float(), refd, atol=4e-3, rtol=2 ** -7)
-    # prefix reuse over the fp8 pool: refused
-    fb2 = H.make_extend_batch(runner, backend, [8], [4], DEV, seed=5)
+    # extend over the cached prefix (prefix rows come from the fp8 pool, new rows from the arguments)
+    lens2 = [l for l in lens]                               # requests 0..2 now hold lens2 tokens in the pool
+    ext2 = [9, 33, 1]
+    pre2 = lens2
+    r2t = runner.req_to_token_pool.req_to_token
+    new_slots, pos = [], 450
+    for i in range(3):
+        sl = torch.arange(pos, pos + ext2[i], dtype=torch.int32)
+        r2t[i, pre2[i]: pre2[i] + ext2[i]] = sl.to(DEV)
+        new_slots.append(sl.to(torch.int64))
+        pos += ext2[i]
+    from types import SimpleNamespace
+    E2 = sum(ext2)
+    fb2 = SimpleNamespace(forward_mode=H.ForwardMode.EXTEND, batch_size=3, req_pool_indices=fb.req_pool_indices,
+                          seq_lens=torch.tensor([p + e for p, e in zip(pre2, ext2)], dtype=torch.int64, device=DEV),
+                          seq_lens_sum=sum(pre2) + E2, seq_lens_cpu=None,
+                          extend_prefix_lens=torch.tensor(pre2, dtype=torch.int32, device=DEV),
+                          extend_seq_lens=torch.tensor(ext2, dtype=torch.int32, device=DEV),
+                          extend_prefix_lens_cpu=pre2, extend_seq_lens_cpu=ext2,
+                          out_cache_loc=torch.cat(new_slots).to(DEV), req_to_token_pool=runner.req_to_token_pool,
+                          token_to_kv_pool=runner.token_to_kv_pool, attn_backend=backend, spec_info=None, positions=None)
+    q2 = torch.randn(E2, Hq * D, generator=g).to(dtype)
+    k2 = torch.randn(E2, Hkv, D, generator=g).to(dtype)
+    v2 = torch.randn(E2, Hkv, D, generator=g).to(dtype)
     backend.init_forward_metadata(fb2)
-    with pytest.raises(NotImplementedError):
-        backend.forward(q[:4].to(DEV), k[:4].to(DEV), v[:4].to(DEV), layer, fb2)
+    o2 = backend.forward(q2.to(DEV), k2.to(DEV), v2.to(DEV), layer, fb2)
+    # oracle: an fp32 pool holding the DEQUANTISED prefix rows and the full-precision new rows
+    kf, vf = k8.float() * 0.5, v8.float() * 2.0
+    kf[torch.cat(new_slots)] = k2.float()
+    vf[torch.cat(new_slots)] = v2.float()
+    ref2 = oa.extend_fp32(q2.view(E2, Hq, D), kf, vf, r2t.cpu(), fb2.req_pool_indices.cpu(), fb2.seq_lens.cpu(),
+                          fb2.extend_prefix_lens.cpu(), fb2.extend_seq_lens.cpu(), D ** -0.5)
+    torch.testing.assert_close(o2.view(E2, Hq, D).cpu().float(), ref2, atol=2e-2, rtol=2e-2)
+    # and the new rows landed in the fp8 pool, quantised with the scales
+    oa.set_kv_buffer_fp8(k8, v8, torch.cat(new_slots), k2, v2, 0.5, 2.0)
+    assert torch.equal(pool.k_buffer[0].cpu(), k8.view(torch.uint8)) and torch.equal(pool.v_buffer[0].cpu(), v8.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k_scale,v_scale,cap,causal", [(1.0, 1.0, 0.0, True), (0.6, 1.7, 0.0, True), (0.6, 1.7, 20.0, True),
+                                                         (0.8, 1.2, 0.0, False)])
+def test_extend_attention_fp8_prefix_vs_oracle(dtype, k_scale, v_scale, cap, causal):
+    """Ragged extend with prefixes in an fp8 pool (through the C ABI) vs the fp32 oracle on the dequantised prefix."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(11)
+    Hq, Hkv, D = 32, 8, 128
+    pre, ext = [0, 70, 33, 129, 5], [17, 1, 64, 40, 100]
+    B, E, P = len(pre), sum(ext), sum(pre)
+    slots = P + E + 1
+    k8 = (torch.randn(slots, Hkv, D, generator=g) / k_scale).clamp(-448, 448).to(FP8)
+    v8 = (torch.randn(slots, Hkv, D, generator=g) / v_scale).clamp(-448, 448).to(FP8)
+    q = torch.randn(E, Hq, D, generator=g).to(dtype)
+    k = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    perm = torch.randperm(slots - 1, generator=g) + 1
+    r2t = torch.zeros(B, max(p + e for p, e in zip(pre, ext)), dtype=torch.int32)
+    off, new_loc = 0, []
+    for i in range(B):
+        n = pre[i] + ext[i]
+        r2t[i, :n] = perm[off: off + n].to(torch.int32)
+        new_loc.append(perm[off + pre[i]: off + n])
+        off += n
+    new_loc = torch.cat(new_loc)
+    kf, vf = k8.float() * k_scale, v8.float() * v_scale
+    kf[new_loc], vf[new_loc] = k.float(), v.float()
+    rpi = torch.arange(B)
+    sl = torch.tensor([p + e for p, e in zip(pre, ext)])
+    ref = oa.extend_fp32(q, kf, vf, r2t, rpi, sl, torch.tensor(pre), torch.tensor(ext), D ** -0.5, causal=causal, logit_cap=cap)
+    pre_t = torch.tensor(pre, dtype=torch.int32, device=DEV)
+    ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    kvp = ops.kv_indptr(pre_t).clone()
+    idx = torch.empty(max(P, 1), dtype=torch.int32, device=DEV)
+    ops.kv_indices(r2t.to(DEV), rpi.to(DEV), pre_t, kvp, idx)
+    qo = ops.kv_indptr(ext_t)
+    o = torch.empty(E, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention_fp8kv(q.to(DEV), k.to(DEV), v.to(DEV), o, k8.to(DEV), v8.view(torch.uint8).to(DEV), k_scale, v_scale,
+                               qo, kvp, idx, max(ext), D ** -0.5, cap, causal, -1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o.cpu().float(), ref, atol=2e-2 * max(1.0, v_scale), rtol=2e-2)
 
 
 def test_fp8kv_full_size_constant_v_identity():
