@@ -39,6 +39,8 @@ SIGNATURES = {
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
+    "mi_extend_attn_masked": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _i64,
+                                     _i64, _i64, _i64, _i64, _i64, _f, _f, _i64, _int, _p]),
     "mi_merge_state": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "mi_fp8_quant_per_tensor": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_fp8_quant_per_token": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),

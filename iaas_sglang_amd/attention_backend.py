@@ -27,6 +27,8 @@ class ForwardMetadata:
     max_extend_len: Optional[int]
     num_kv_splits: int
     workspace: Optional[torch.Tensor]
+    custom_mask: Optional[torch.Tensor] = None      # TARGET_VERIFY: flat tree mask (triton_backend.py:253-260)
+    mask_indptr: Optional[torch.Tensor] = None
 
 
 class MiAttnBackend(AttentionBackend):
@@ -48,6 +50,8 @@ class MiAttnBackend(AttentionBackend):
         if getattr(model_runner, "sliding_window_size", None):
             raise NotImplementedError("MiAttnBackend: sliding-window models are not wired yet")
         self.skip_prefill = skip_prefill
+        self.num_draft_tokens = getattr(sa, "speculative_num_draft_tokens", None)
+        self.mask_indptr = torch.zeros(max_bs + 1, dtype=torch.int64, device=self.device)
         self.kv_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
         self.qo_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
         self.cu_count = max(ops.cu_count(), 1)
@@ -88,8 +92,26 @@ class MiAttnBackend(AttentionBackend):
     def init_forward_metadata(self, forward_batch):
         bs = forward_batch.batch_size
         mode = forward_batch.forward_mode
-        if getattr(forward_batch, "spec_info", None) is not None or mode.is_target_verify() or mode.is_draft_extend():
-            raise NotImplementedError("MiAttnBackend: speculative decoding modes are out of scope")
+        spec_info = getattr(forward_batch, "spec_info", None)
+        if mode.is_draft_extend() or (spec_info is not None and not mode.is_target_verify()):
+            raise NotImplementedError("MiAttnBackend: draft-side speculative modes (DRAFT_EXTEND, draft decode) are out "
+                                      "of scope; TARGET_VERIFY is supported")
+        if mode.is_target_verify():
+            # triton_backend.py:226-263: every request verifies num_draft_tokens tree nodes against its whole
+            # committed sequence ("prefix" = seq_lens) under spec_info.custom_mask
+            nd = int(self.num_draft_tokens or 0)
+            if nd <= 0 or spec_info is None or getattr(spec_info, "custom_mask", None) is None:
+                raise ValueError("TARGET_VERIFY needs server_args.speculative_num_draft_tokens and spec_info.custom_mask")
+            qo_indptr = torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int32, device=self.device)
+            kv_indptr = ops.kv_indptr(forward_batch.seq_lens, self.kv_indptr)
+            kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum), 1), dtype=torch.int32, device=self.device)
+            ops.kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr, kv_indices)
+            seq_mask_len = nd * (forward_batch.seq_lens.to(torch.int64) + nd)
+            mask_indptr = self.mask_indptr
+            mask_indptr[1: bs + 1] = torch.cumsum(seq_mask_len[:bs], dim=0)     # plumbing, as the reference does it
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, nd, 1, None,
+                                                    custom_mask=spec_info.custom_mask, mask_indptr=mask_indptr[: bs + 1])
+            return
         if mode.is_decode_or_idle():
             kv_indptr = ops.kv_indptr(forward_batch.seq_lens, self.kv_indptr)
             kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum), 1), dtype=torch.int32, device=self.device)
@@ -217,6 +239,17 @@ class MiAttnBackend(AttentionBackend):
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
         window = getattr(layer, "sliding_window_size", -1)
         window = -1 if window is None else int(window)
+        if md.custom_mask is not None:
+            if k_buf.element_size() == 1:
+                raise NotImplementedError("MiAttnBackend: TARGET_VERIFY over an fp8 KV pool is not wired")
+            ops.extend_attention_masked(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                                        k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                                        v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
+                                        o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
+                                        md.kv_indptr, md.kv_indices, md.custom_mask, md.mask_indptr, md.max_extend_len,
+                                        layer.scaling, getattr(layer, "logit_cap", 0.0) or 0.0, True,
+                                        window if window > 0 else -1)
+            return o
         if k_buf.element_size() == 1:
             # fp8 pool: the cached prefix is read (and converted) from the pool; the new tokens are attended from
             # the T-typed k/v arguments, exactly as in the bf16 case (they were just written to the pool in fp8)

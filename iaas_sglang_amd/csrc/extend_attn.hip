@@ -33,6 +33,12 @@ struct ExtendParams {
   int64_t sliding_window;
   float scale_log2, sm_scale, logit_cap;
   float k_scale, v_scale;   // fp8 pool (KV8): prefix keys are k8 * k_scale, prefix values v8 * v_scale
+  // speculative-decode tree mask (extend_attention.py:93-94,168-178,245-257): request i's mask is a row-major
+  // [ext_len_i, prefix_i + ext_len_i] byte matrix at custom_mask + mask_indptr[i]; it REPLACES the causal rule on
+  // the new-token keys; prefix keys are all visible when skip_prefix_mask (the reference's default)
+  const uint8_t* custom_mask;
+  const int64_t* mask_indptr;
+  int32_t skip_prefix_mask;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -99,7 +105,11 @@ void extend_attn_kernel(const ExtendParams p) {
 
   // keys this workgroup needs: prefix + (causal ? tokens up to the block's last : all)
   const int32_t blk_last = min(ext_len, (qb + 1) * BQ);
-  const int32_t n_keys = prefix + (p.causal ? blk_last : ext_len);
+  const bool masked = p.custom_mask != nullptr;
+  const bool causal = p.causal && !masked;
+  const int32_t n_keys = prefix + (causal ? blk_last : ext_len);
+  const int64_t mask_base = masked ? p.mask_indptr[req] : 0;
+  const int32_t seq_len = prefix + ext_len;
   const int32_t n_tiles = (n_keys + KT - 1) / KT;
 
   // ---- staging: thread -> (row srow + TPR*pass, 16-byte chunk schunk); registers between global and LDS
@@ -157,7 +167,7 @@ void extend_attn_kernel(const ExtendParams p) {
     for (int db = 0; db < DB; ++db) acc[rt][db] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // last key (exclusive) this WAVE can see: lets early waves skip fully masked sub-tiles
-  const int32_t wave_keys = p.causal ? prefix + min(ext_len, tok0 + 16 * RT) : n_keys;
+  const int32_t wave_keys = causal ? prefix + min(ext_len, tok0 + 16 * RT) : n_keys;
 
 #pragma unroll
   for (int sub = 0; sub < NSUB; ++sub) {
@@ -177,7 +187,8 @@ void extend_attn_kernel(const ExtendParams p) {
       const int32_t kbase = tile * KT + sub * 32;
       if (wave_active && kbase < wave_keys) {
         // every key of the sub-tile visible to every row of the wave?  (then no mask arithmetic at all)
-        const bool all_visible = kbase + 31 < n_keys && (!p.causal || kbase + 31 <= prefix + tok0) && p.sliding_window <= 0;
+        const bool all_visible = kbase + 31 < n_keys && (!causal || kbase + 31 <= prefix + tok0) && p.sliding_window <= 0 &&
+                                 (!masked || (p.skip_prefix_mask && kbase + 31 < prefix));
         // ---- S^T = K . Q^T for the two 16-key halves of the sub-tile; each K fragment feeds the RT row tiles
         f32x4 s[RT][2];
 #pragma unroll
@@ -224,7 +235,9 @@ void extend_attn_kernel(const ExtendParams p) {
               if (!all_visible) {   // wave-uniform: only diagonal / last / windowed sub-tiles pay for the mask
                 const int32_t kp = kbase + 16 * h + 4 * g4 + r;
                 bool ok = kp < n_keys;
-                if (p.causal) ok = ok && (kp <= q_pos[rt]);
+                if (causal) ok = ok && (kp <= q_pos[rt]);
+                if (masked && ok && !(p.skip_prefix_mask && kp < prefix))
+                  ok = p.custom_mask[mask_base + (int64_t)(q_pos[rt] - prefix) * seq_len + kp] != 0;
                 if (p.sliding_window > 0) ok = ok && ((int64_t)q_pos[rt] <= (int64_t)kp + p.sliding_window);
                 x = ok ? x : -INFINITY;
               }
@@ -346,7 +359,9 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
                             int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                             int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
                             int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
-                            int64_t sliding_window, int dtype, void* stream, bool kv8, float k_scale, float v_scale) {
+                            int64_t sliding_window, int dtype, void* stream, bool kv8, float k_scale, float v_scale,
+                            const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
+                            int skip_prefix_mask = 1) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
   MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
@@ -369,6 +384,8 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   p.sliding_window = sliding_window; p.sm_scale = sm_scale; p.logit_cap = logit_cap;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.k_scale = k_scale; p.v_scale = v_scale;
+  MI_CHECK_ARG(!custom_mask || mask_indptr);
+  p.custom_mask = custom_mask; p.mask_indptr = mask_indptr; p.skip_prefix_mask = skip_prefix_mask;
   hipStream_t st = (hipStream_t)stream;
   if (kv8) {
     MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
@@ -411,4 +428,19 @@ extern "C" int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const 
                           num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
                           stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype, stream, true,
                           k_scale, v_scale);
+}
+
+extern "C" int mi_extend_attn_masked(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                                     const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                                     const int32_t* kv_indptr, const int32_t* kv_indices, const uint8_t* custom_mask,
+                                     const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t batch,
+                                     int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                     int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_kx_tok,
+                                     int64_t stride_vx_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                                     float logit_cap, int64_t sliding_window, int dtype, void* stream) {
+  MI_CHECK_ARG(custom_mask != nullptr && mask_indptr != nullptr);
+  return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, max_extend_len,
+                          num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
+                          stride_k_slot, stride_v_slot, sm_scale, logit_cap, 0, sliding_window, dtype, stream, false, 1.f,
+                          1.f, custom_mask, mask_indptr, skip_prefix_custom_mask);
 }

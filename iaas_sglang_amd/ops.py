@@ -193,6 +193,29 @@ def extend_attention_fp8kv(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Te
     return o
 
 
+def extend_attention_masked(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
+                            k_buf: torch.Tensor, v_buf: torch.Tensor, qo_indptr: torch.Tensor,
+                            kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, custom_mask: torch.Tensor,
+                            mask_indptr: torch.Tensor, max_extend_len: int, sm_scale: float, logit_cap: float = 0.0,
+                            skip_prefix_custom_mask: bool = True, sliding_window: int = -1) -> torch.Tensor:
+    """extend_attention with a tree mask (bool / uint8, flat; request i at mask_indptr[i], [ext_i, pre_i + ext_i])."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, o, k_ext, v_ext, k_buf, v_buf):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    assert qo_indptr.dtype == torch.int32 and kv_indptr_t.dtype == torch.int32 and kv_indices_t.dtype == torch.int32
+    assert custom_mask.dtype in (torch.bool, torch.uint8) and custom_mask.is_contiguous()
+    assert mask_indptr.dtype == torch.int64 and mask_indptr.numel() >= B + 1
+    check(lib.mi_extend_attn_masked(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o), _ptr(k_buf), _ptr(v_buf), _ptr(qo_indptr),
+                                    _ptr(kv_indptr_t), _ptr(kv_indices_t), _ptr(custom_mask), _ptr(mask_indptr),
+                                    int(skip_prefix_custom_mask), B, int(max_extend_len), Hq, Hkv, D, q.stride(0),
+                                    o.stride(0), k_ext.stride(0), v_ext.stride(0), k_buf.stride(0), v_buf.stride(0),
+                                    float(sm_scale), float(logit_cap), int(sliding_window), _dt(q), _stream()),
+          "mi_extend_attn_masked")
+    return o
+
+
 def merge_state(o_a, lse_a, o_b, lse_b, out=None, out_lse=None) -> Tuple[torch.Tensor, torch.Tensor]:
     n, h, d = o_a.shape
     assert o_a.is_contiguous() and o_b.is_contiguous() and lse_a.is_contiguous() and lse_b.is_contiguous()

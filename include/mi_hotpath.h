@@ -162,6 +162,24 @@ int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const void* v_ext
                          int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                          int64_t sliding_window, int dtype, void* stream);
 
+/* mi_extend_attn with a per-request visibility mask on the NEW-token keys instead of the causal rule
+ * (speculative-decode tree verification): request i's mask is a row-major byte matrix
+ * [ext_len_i, prefix_i + ext_len_i] at custom_mask + mask_indptr[i] (non-zero = visible); prefix keys are all
+ * visible when skip_prefix_custom_mask (the reference's default), else masked by the same matrix.
+ * replaces: extend_attention_fwd(custom_mask, mask_indptr, skip_prefix_custom_mask),
+ * triton_ops/extend_attention.py:93-94,168-178,245-257,306-438 as called for TARGET_VERIFY,
+ * triton_backend.py:226-263,632-685. */
+int mi_extend_attn_masked(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                          const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                          const int32_t* kv_indptr, const int32_t* kv_indices,
+                          const uint8_t* custom_mask, const int64_t* mask_indptr,
+                          int skip_prefix_custom_mask, int64_t batch, int64_t max_extend_len,
+                          int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                          int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_kx_tok,
+                          int64_t stride_vx_tok, int64_t stride_k_slot, int64_t stride_v_slot,
+                          float sm_scale, float logit_cap, int64_t sliding_window, int dtype,
+                          void* stream);
+
 /* out = (a*e^{la} + b*e^{lb}) / (e^{la}+e^{lb}); out_lse = log(e^{la}+e^{lb})  (lse fp32, may be null)
  *   a,b,out [n,h,d] contiguous; lse [n,h].
  * replaces: merge_state_v2, sgl-kernel/csrc/attention/merge_attn_states.cu:31-106,182-204. */

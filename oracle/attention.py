@@ -190,11 +190,15 @@ def decode_fp32(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens,
 
 def extend_fp32(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens,
                 extend_prefix_lens, extend_seq_lens, scaling=None, causal=True,
-                logit_cap=0.0, sliding_window=-1):
+                logit_cap=0.0, sliding_window=-1, custom_mask=None, mask_indptr=None,
+                skip_prefix_custom_mask=True):
     """fp32 restatement of extend: row j of request i (global position
     pre_i + j) attends keys 0..pre_i+j (causal) or all S_i keys (non-causal).
     sliding_window >0 keeps keys with q_pos <= k_pos + window
-    (triton_ops/extend_attention.py:182-187)."""
+    (triton_ops/extend_attention.py:182-187).
+    custom_mask (speculative tree verification, extend_attention.py:93-94,168-178,245-257): flat bool;
+    request i owns [ext_i, S_i] row-major at mask_indptr[i]; it REPLACES the causal rule on the new-token
+    keys, and masks the prefix keys too unless skip_prefix_custom_mask (the reference's default)."""
     B = int(seq_lens.shape[0])
     Hq, D = q.shape[1], q.shape[2]
     Hkv, Dv = k_cache.shape[1], v_cache.shape[-1]
@@ -212,7 +216,13 @@ def extend_fp32(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens,
         qpos = torch.arange(pre, pre + ext).view(1, ext, 1)
         kpos = torch.arange(S).view(1, 1, S)
         mask = torch.ones(1, ext, S, dtype=torch.bool)
-        if causal:
+        if custom_mask is not None:
+            m0 = int(mask_indptr[i])
+            cm = custom_mask[m0: m0 + ext * S].to(torch.bool).view(1, ext, S).clone()
+            if skip_prefix_custom_mask:
+                cm[:, :, :pre] = True
+            mask = mask & cm
+        elif causal:
             mask = mask & (kpos <= qpos)
         if sliding_window is not None and sliding_window > 0:
             mask = mask & (qpos <= kpos + sliding_window)

@@ -380,3 +380,138 @@ def test_decode_and_extend_with_paged_slots(page_size):
     oute, kca, vca = _run_extend(None, qe, kn, vn, k, v, r2t, rpi, pre, ext, D ** -0.5, True)
     refe = oa.extend_fp32(qe, kca, vca, r2t, rpi, sl, pre, ext, scaling=D ** -0.5)
     torch.testing.assert_close(oute.float(), refe, atol=4e-3, rtol=2 ** -6)
+
+
+# ---------------------------------------------------------------------------------------------
+# speculative-decode tree mask (custom_mask) in extend -- SURVEY 8a row extend_attention_fwd / 8f row 4
+def _tree_case(g, B, nd, Hq, Hkv, D, dtype, max_seq):
+    from iaas_sglang_amd import ops
+    seq = torch.randint(1, max_seq, (B,), generator=g)
+    P, E = int(seq.sum()), B * nd
+    slots = P + E + 1
+    kc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    vc = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    q = torch.randn(E, Hq, D, generator=g).to(dtype)
+    k = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    perm = torch.randperm(slots - 1, generator=g) + 1
+    r2t = torch.zeros(B, max_seq + nd, dtype=torch.int32)
+    off, new_loc = 0, []
+    for i in range(B):
+        n = int(seq[i]) + nd
+        r2t[i, :n] = perm[off: off + n].to(torch.int32)
+        new_loc.append(perm[off + int(seq[i]): off + n])
+        off += n
+    new_loc = torch.cat(new_loc)
+    kc[new_loc], vc[new_loc] = k, v                       # the oracle reads the new rows back from the pool
+    return seq, q, k, v, kc, vc, r2t, new_loc
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,nd,Hq,Hkv,D,skip_prefix", [(5, 8, 32, 8, 128, True), (3, 4, 8, 8, 64, True), (4, 16, 16, 4, 128, False),
+                                                       (2, 64, 4, 2, 128, True)])
+def test_extend_custom_mask_tree_verify_vs_oracle(dtype, B, nd, Hq, Hkv, D, skip_prefix):
+    """Random tree masks (every draft row sees itself so no row is fully masked), prefix visible or masked."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(B * nd + Hq)
+    seq, q, k, v, kc, vc, r2t, _ = _tree_case(g, B, nd, Hq, Hkv, D, dtype, 90)
+    masks, mptr = [], [0]
+    for i in range(B):
+        S = int(seq[i]) + nd
+        m = torch.rand(nd, S, generator=g) < 0.6
+        m[torch.arange(nd), int(seq[i]) + torch.arange(nd)] = True         # a node always sees itself
+        if not skip_prefix:
+            m[:, 0] = True                                                 # keep at least one prefix key per row
+        masks.append(m.reshape(-1))
+        mptr.append(mptr[-1] + nd * S)
+    custom_mask = torch.cat(masks)
+    mask_indptr = torch.tensor(mptr, dtype=torch.int64)
+    rpi = torch.arange(B)
+    ext = torch.full((B,), nd, dtype=torch.int64)
+    ref = oa.extend_fp32(q, kc, vc, r2t, rpi, seq + nd, seq, ext, D ** -0.5, causal=True, custom_mask=custom_mask,
+                         mask_indptr=mask_indptr, skip_prefix_custom_mask=skip_prefix)
+    seq_d = seq.to(torch.int32).to(DEV)
+    kvp = ops.kv_indptr(seq_d).clone()
+    idx = torch.empty(int(seq.sum()), dtype=torch.int32, device=DEV)
+    ops.kv_indices(r2t.to(DEV), rpi.to(DEV), seq_d, kvp, idx)
+    qo = torch.arange(0, (B + 1) * nd, nd, dtype=torch.int32, device=DEV)
+    o = torch.empty_like(q).to(DEV)
+    ops.extend_attention_masked(q.to(DEV), k.to(DEV), v.to(DEV), o, kc.to(DEV), vc.to(DEV), qo, kvp, idx, custom_mask.to(DEV),
+                                mask_indptr.to(DEV), nd, D ** -0.5, 0.0, skip_prefix)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o.cpu().float(), ref, atol=2e-2, rtol=2e-2)
+
+
+def test_extend_custom_mask_equal_to_causal_reproduces_causal():
+    """The reference's own check (test_triton_attention_kernels.py: a lower-triangular custom mask == causal)."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, nd, Hq, Hkv, D, dtype = 3, 40, 32, 8, 128, torch.bfloat16
+    seq, q, k, v, kc, vc, r2t, _ = _tree_case(g, B, nd, Hq, Hkv, D, dtype, 70)
+    masks, mptr = [], [0]
+    for i in range(B):
+        S = int(seq[i]) + nd
+        m = torch.zeros(nd, S, dtype=torch.bool)
+        m[:, : int(seq[i])] = True
+        m[:, int(seq[i]):] = torch.tril(torch.ones(nd, nd, dtype=torch.bool))
+        masks.append(m.reshape(-1)); mptr.append(mptr[-1] + nd * S)
+    rpi = torch.arange(B)
+    seq_d = seq.to(torch.int32).to(DEV)
+    kvp = ops.kv_indptr(seq_d).clone()
+    idx = torch.empty(int(seq.sum()), dtype=torch.int32, device=DEV)
+    ops.kv_indices(r2t.to(DEV), rpi.to(DEV), seq_d, kvp, idx)
+    qo = torch.arange(0, (B + 1) * nd, nd, dtype=torch.int32, device=DEV)
+    args = (q.to(DEV), k.to(DEV), v.to(DEV))
+    o1, o2 = torch.empty_like(q).to(DEV), torch.empty_like(q).to(DEV)
+    ops.extend_attention(*args, o1, kc.to(DEV), vc.to(DEV), qo, kvp, idx, nd, D ** -0.5, 0.0, True, -1)
+    ops.extend_attention_masked(*args, o2, kc.to(DEV), vc.to(DEV), qo, kvp, idx, torch.cat(masks).to(DEV),
+                                torch.tensor(mptr, dtype=torch.int64, device=DEV), nd, D ** -0.5, 0.0, False)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+
+
+def test_backend_target_verify_mode():
+    """MiAttnBackend in TARGET_VERIFY: metadata as triton_backend.py:226-263, draft K/V written at out_cache_loc, tree mask."""
+    from types import SimpleNamespace
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype, nd = H.TINY, torch.bfloat16, 4
+    Hq, Hkv, D = shape.num_heads, shape.num_kv_heads, shape.head_dim
+    runner = H.make_runner(shape, max_reqs=4, ctx=128, pool_tokens=400, dtype=dtype, device=DEV, fill_kv=True)
+    runner.server_args.speculative_num_draft_tokens = nd
+    backend = MiAttnBackend(runner)
+    g = torch.Generator().manual_seed(9)
+    seq = [30, 7, 64]
+    B = len(seq)
+    r2t = runner.req_to_token_pool.req_to_token
+    slot, loc = 1, []
+    for i, s_ in enumerate(seq):
+        r2t[i, : s_ + nd] = torch.arange(slot, slot + s_ + nd, dtype=torch.int32, device=DEV)
+        loc.append(torch.arange(slot + s_, slot + s_ + nd)); slot += s_ + nd
+    loc = torch.cat(loc)
+    masks = []
+    for s_ in seq:
+        m = torch.rand(nd, s_ + nd, generator=g) < 0.5
+        m[torch.arange(nd), s_ + torch.arange(nd)] = True
+        masks.append(m.reshape(-1))
+    cm = torch.cat(masks)
+    fb = SimpleNamespace(forward_mode=H.ForwardMode.TARGET_VERIFY, batch_size=B,
+                         req_pool_indices=torch.arange(B, dtype=torch.int64, device=DEV),
+                         seq_lens=torch.tensor(seq, dtype=torch.int64, device=DEV), seq_lens_sum=sum(seq), seq_lens_cpu=None,
+                         out_cache_loc=loc.to(DEV), req_to_token_pool=runner.req_to_token_pool,
+                         token_to_kv_pool=runner.token_to_kv_pool, attn_backend=backend,
+                         spec_info=SimpleNamespace(custom_mask=cm.to(DEV)), positions=None)
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    q = torch.randn(B * nd, Hq * D, generator=g).to(dtype)
+    k = torch.randn(B * nd, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(B * nd, Hkv, D, generator=g).to(dtype)
+    pool = runner.token_to_kv_pool
+    kc, vc = pool.k_buffer[0].cpu().clone(), pool.v_buffer[0].cpu().clone()
+    backend.init_forward_metadata(fb)
+    o = backend.forward(q.to(DEV), k.to(DEV), v.to(DEV), layer, fb)
+    oa.set_kv_buffer(kc, vc, loc, k, v)
+    mptr = torch.tensor([0] + [nd * (s_ + nd) for s_ in seq]).cumsum(0)
+    ref = oa.extend_fp32(q.view(-1, Hq, D), kc, vc, r2t.cpu(), torch.arange(B), torch.tensor(seq) + nd, torch.tensor(seq),
+                         torch.full((B,), nd), D ** -0.5, custom_mask=cm, mask_indptr=mptr)
+    torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=2e-2, rtol=2e-2)
+    assert torch.equal(pool.k_buffer[0].cpu().view(torch.int16), kc.view(torch.int16))

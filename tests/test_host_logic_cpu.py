@@ -79,9 +79,12 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     assert be._choose_splits(1, 100) == 1                    # never split below ~256 keys
     assert be._choose_splits(1, 100000) == 8                 # capped by --triton-attention-num-kv-splits
     assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
-    fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.TARGET_VERIFY, spec_info=None)
+    fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.DRAFT_EXTEND, spec_info=None)
     with pytest.raises(NotImplementedError):
-        be.init_forward_metadata(fb)                          # speculative modes: out of scope, loud
+        be.init_forward_metadata(fb)                          # draft-side speculative modes: out of scope, loud
+    fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.TARGET_VERIFY, spec_info=None)
+    with pytest.raises(ValueError):
+        be.init_forward_metadata(fb)                          # verify without a tree mask / draft count: loud
     r = _fake_runner()
     r.sliding_window_size = 4096
     with pytest.raises(NotImplementedError):

@@ -12,6 +12,8 @@ dev = "cuda"
 M = int(os.environ.get("M", "128"))
 pad = int(os.environ.get("XPAD", "0"))
 shapes = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]
+if os.environ.get("SHAPES"):   # e.g. SHAPES="768x4096,4096x512,3584x4096,4096x1792" (N x K; TP=8 per-rank shapes)
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 nbuf = 6
 for N, K in shapes:
     ws = [torch.randn(N, K, device=dev).to(FP8) for _ in range(nbuf)]      # rotate buffers: defeat the L3
