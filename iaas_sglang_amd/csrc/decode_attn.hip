@@ -29,6 +29,7 @@ struct DecodeParams {
   float* ws_o;   // [B][Hq][splits][D]
   float* ws_ml;  // [B][Hq][splits][2]
   int32_t num_q_heads, num_kv_heads, group, num_splits;
+  int32_t split_chunk;   // > 0: every split covers this many keys (multiple of 16) unless the request needs more
   int64_t stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot;
   float scale_log2;  // sm_scale * log2(e)   (logit_cap == 0)
   float sm_scale, logit_cap;
@@ -109,9 +110,12 @@ void decode_attn_kernel(const DecodeParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int row = lane >> 4, col = lane & 15;
-  const int s = blockIdx.x;
+  // request index fastest: consecutive workgroups (which the hardware deals round-robin to the 8 XCDs) are
+  // different requests of the SAME split, so the non-empty splits of a ragged batch spread over all XCDs
+  // (with the split index fastest, fixed-size splits s = 0..k of every request landed on XCDs 0..k only)
+  const int b = blockIdx.x;
   const int hk = blockIdx.y * W + wave;
-  const int b = blockIdx.z;
+  const int s = blockIdx.z;
   if (hk >= p.num_kv_heads) return;
   const int group = p.group;
   const int nsplit = p.num_splits;
@@ -120,6 +124,9 @@ void decode_attn_kernel(const DecodeParams p) {
   const int32_t S = p.kv_indptr[b + 1] - base;
   int32_t per = (S + nsplit - 1) / nsplit;
   per = (per + 15) & ~15;
+  // fixed-size splits balance RAGGED batches (every non-empty workgroup walks <= split_chunk keys, short requests
+  // leave their trailing splits empty); a request longer than nsplit * split_chunk falls back to S / nsplit
+  per = max(per, p.split_chunk);
   const int32_t start = s * per;
   const int32_t end = min(S, start + per);
   const int hq0 = hk * group;
@@ -420,7 +427,7 @@ static int env_int(const char* name, int dflt) {
 
 template <typename T, int D, int G, int W, bool KV8>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
-  dim3 grid((unsigned)p.num_splits, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)batch);
+  dim3 grid((unsigned)batch, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)p.num_splits);
   decode_attn_kernel<T, D, G, W, KV8><<<grid, W * 64, 0, st>>>(p);
 }
 
@@ -453,7 +460,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
                             int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                             int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                             int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                            float logit_cap, int64_t num_splits, int dtype, void* stream, void* o_fp8,
+                            float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream, void* o_fp8,
                             const float* o_scale, bool kv8 = false, float k_scale = 1.f, float v_scale = 1.f) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
@@ -462,6 +469,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
   MI_CHECK_ARG(num_splits >= 1 && num_splits <= 65535 && batch <= 65535);
   MI_CHECK_ARG(num_splits == 1 || workspace != nullptr);
+  MI_CHECK_ARG(split_chunk >= 0 && split_chunk % 16 == 0 && split_chunk < (1 << 30));
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (head_dim != 64 && head_dim != 128)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_decode_attn: head_dim %lld not supported (64, 128)", (long long)head_dim);
@@ -481,6 +489,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   p.ws_ml = p.ws_o ? p.ws_o + batch * num_q_heads * num_splits * head_dim : nullptr;
   p.num_q_heads = (int32_t)num_q_heads; p.num_kv_heads = (int32_t)num_kv_heads;
   p.group = (int32_t)(num_q_heads / num_kv_heads); p.num_splits = (int32_t)num_splits;
+  p.split_chunk = (int32_t)split_chunk;
   p.stride_q_tok = stride_q_tok; p.stride_o_tok = stride_o_tok;
   p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
   // fp8 KV: logits = sm_scale * k_scale * (q . k8), out = v_scale * softmax . v8
@@ -524,10 +533,10 @@ extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_bu
                               int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                               int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                               int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                              float logit_cap, int64_t num_splits, int dtype, void* stream) {
+                              float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
   MI_CHECK_ARG(o != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
                           stream, nullptr, nullptr);
 }
 
@@ -536,10 +545,10 @@ extern "C" int mi_decode_attn_fp8out(const void* q, const void* k_buf, const voi
                                      const int32_t* kv_indices, void* workspace, int64_t batch, int64_t num_q_heads,
                                      int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                                      int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
-                                     int64_t num_splits, int dtype, void* stream) {
+                                     int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
   MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
                           stream, o_fp8, o_scale);
 }
 
@@ -548,8 +557,8 @@ extern "C" int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void
                                     const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace, int64_t batch,
                                     int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                                     int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                                    float logit_cap, int64_t num_splits, int dtype, void* stream) {
+                                    float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
                           stream, o_fp8, o_scale, true, k_scale, v_scale);
 }

@@ -131,8 +131,8 @@ def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_sp
 def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o: torch.Tensor,
                      kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, sm_scale: float,
                      logit_cap: float = 0.0, num_splits: int = 1,
-                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q,o [B,Hq,D]; k_buf,v_buf [slots,Hkv,D]; split-KV token attention."""
+                     workspace: Optional[torch.Tensor] = None, split_chunk: int = 0) -> torch.Tensor:
+    """q,o [B,Hq,D]; k_buf,v_buf [slots,Hkv,D]; split-KV token attention (split_chunk: keys per split, 0 = S/splits)."""
     B, Hq, D = q.shape
     Hkv = k_buf.shape[1]
     assert q.stride(2) == 1 and q.stride(1) == D and o.stride(2) == 1 and o.stride(1) == D
@@ -145,7 +145,7 @@ def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, 
     check(lib.mi_decode_attn(_ptr(q), _ptr(k_buf), _ptr(v_buf), _ptr(o), _ptr(kv_indptr_t), _ptr(kv_indices_t),
                              _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0), o.stride(0),
                              k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap),
-                             int(num_splits), _dt(q), _stream()), "mi_decode_attn")
+                             int(num_splits), int(split_chunk), _dt(q), _stream()), "mi_decode_attn")
     return o
 
 
@@ -407,7 +407,8 @@ def silu_and_mul_fp8(x: torch.Tensor, q_scale: torch.Tensor) -> torch.Tensor:
 def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o_fp8: torch.Tensor,
                             o_scale: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,
                             sm_scale: float, logit_cap: float = 0.0, num_splits: int = 1,
-                            workspace: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            workspace: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None,
+                            split_chunk: int = 0) -> torch.Tensor:
     """decode_attention whose output stage also quantises for the following static-scale FP8 linear:
     o_fp8 [B, Hq*D] = quant(o, o_scale), bit-identical to decode_attention + fp8_quant_per_tensor(scale)."""
     B, Hq, D = q.shape
@@ -426,7 +427,7 @@ def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.T
                                     _ptr(kv_indptr_t), _ptr(kv_indices_t),
                                     _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
                                     o.stride(0) if o is not None else Hq * D, k_buf.stride(0), v_buf.stride(0),
-                                    float(sm_scale), float(logit_cap), int(num_splits), _dt(q), _stream()),
+                                    float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), _dt(q), _stream()),
           "mi_decode_attn_fp8out")
     return o_fp8
 
@@ -435,7 +436,7 @@ def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.
                            kv_indices_t: torch.Tensor, sm_scale: float, k_scale: float = 1.0, v_scale: float = 1.0,
                            logit_cap: float = 0.0, num_splits: int = 1, workspace: Optional[torch.Tensor] = None,
                            o: Optional[torch.Tensor] = None, o_fp8: Optional[torch.Tensor] = None,
-                           o_scale: Optional[torch.Tensor] = None):
+                           o_scale: Optional[torch.Tensor] = None, split_chunk: int = 0):
     """Decode attention over an fp8 (e4m3fn / uint8 storage) KV pool [slots, Hkv, 128]."""
     B, Hq, D = q.shape
     Hkv = k_buf8.shape[1]
@@ -454,7 +455,7 @@ def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.
                                    float(k_scale), float(v_scale), _ptr(kv_indptr_t), _ptr(kv_indices_t),
                                    _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
                                    o.stride(0) if o is not None else Hq * D, k_buf8.stride(0), v_buf8.stride(0),
-                                   float(sm_scale), float(logit_cap), int(num_splits), _dt(q), _stream()),
+                                   float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), _dt(q), _stream()),
           "mi_decode_attn_fp8kv")
     return o if o is not None else o_fp8
 

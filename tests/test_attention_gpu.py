@@ -515,3 +515,32 @@ def test_backend_target_verify_mode():
                          torch.full((B,), nd), D ** -0.5, custom_mask=cm, mask_indptr=mptr)
     torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=2e-2, rtol=2e-2)
     assert torch.equal(pool.k_buffer[0].cpu().view(torch.int16), kc.view(torch.int16))
+
+
+@pytest.mark.parametrize("chunk,splits", [(16, 8), (64, 8), (256, 4), (64, 2), (1024, 3)])
+def test_decode_fixed_chunk_splits_on_ragged_batch(chunk, splits):
+    """split_chunk: every split covers `chunk` keys; short requests leave trailing splits empty, a request longer
+    than splits * chunk falls back to S / splits (case (64, 2) with 700 keys).  Same math as any other split plan."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(chunk + splits)
+    Hq, Hkv, D, dtype = 32, 8, 128, torch.bfloat16
+    lens = [1, 700, 130, 17, 64, 65, 300, 511]
+    B, total = len(lens), sum(lens)
+    kb = torch.randn(total + 1, Hkv, D, generator=g).to(dtype)
+    vb = torch.randn(total + 1, Hkv, D, generator=g).to(dtype)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    perm = torch.randperm(total, generator=g) + 1
+    r2t = torch.zeros(B, max(lens), dtype=torch.int32)
+    off = 0
+    for i, L in enumerate(lens):
+        r2t[i, :L] = perm[off:off + L].to(torch.int32); off += L
+    rpi, sl = torch.arange(B), torch.tensor(lens)
+    ref = oa.decode_fp32(q, kb, vb, r2t, rpi, sl, scaling=D ** -0.5)
+    indptr = ops.kv_indptr(sl.to(DEV))
+    idx = torch.empty(total, dtype=torch.int32, device=DEV)
+    ops.kv_indices(r2t.to(DEV), rpi.to(DEV), sl.to(DEV), indptr, idx)
+    ws = torch.empty(ops.decode_workspace_numel(B, Hq, D, splits), dtype=torch.float32, device=DEV)
+    o = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+    ops.decode_attention(q.to(DEV), kb.to(DEV), vb.to(DEV), o, indptr, idx, D ** -0.5, 0.0, splits, ws, split_chunk=chunk)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o.cpu().float(), ref, atol=2e-3, rtol=2 ** -7)

@@ -21,20 +21,29 @@ q = torch.randn(B, Hq, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
 o = torch.empty_like(q)
 g = torch.Generator(device=dev).manual_seed(0)
 idx = (torch.arange(B * S, device=dev) if contig else torch.randperm(B * S, device=dev, generator=g)).to(torch.int32) + 1
-sl = torch.full((B,), S, dtype=torch.int64, device=dev)
+if os.environ.get("RAGGED", "0") == "1":      # S_i ~ U[1, 2S], mean S (SURVEY 8d ragged variant), same pool size
+    gl = torch.Generator().manual_seed(0)
+    lens = torch.randint(1, 2 * S + 1, (B,), generator=gl)
+    while int(lens.sum()) > B * S:
+        lens = (lens.float() * 0.98).long().clamp(min=1)
+    sl = lens.to(torch.int64).to(dev)
+else:
+    sl = torch.full((B,), S, dtype=torch.int64, device=dev)
 indptr = ops.kv_indptr(sl)
-abytes = 2 * B * S * Hkv * D * 2 + 2 * B * Hq * D * 2 + 4 * B * S
+tot = int(sl.sum())
+abytes = 2 * tot * Hkv * D * 2 + 2 * B * Hq * D * 2 + 4 * tot
+print(f"tokens {tot} max {int(sl.max())} min {int(sl.min())}", flush=True)
 for ns in [int(x) for x in os.environ.get("SPLITS", "1,2,4,8").split(",")]:
     ws = torch.empty(max(1, ops.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=dev)
     for k, v in pools:
-        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws)
+        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=int(os.environ.get('CHUNK', '0')))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
     e0.record()
     for _ in range(reps):
         for k, v in pools:
-            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws)
+            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=int(os.environ.get('CHUNK', '0')))
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * npool)
     print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} contig={int(contig)} splits={ns} W={os.environ.get('MI_DECODE_W','auto')}: "
