@@ -78,3 +78,68 @@ def test_paged_allocator_class_on_device():
     assert big is None and a.available_size() == (64 - 5) * ps
     a.free(idx)
     assert a.available_size() == (64 - 1) * ps      # the decode token of request 1 still holds its page
+
+
+def test_backend_over_paged_allocator_page64_extend_then_decode():
+    """The reference's page_size=64 case (test_flashattn_backend.py:324-346) on our stack: slots come from
+    PagedTokenToKVPoolAllocator.alloc_extend / alloc_decode (page-contiguous per request), the attention kernels are
+    token-granular so the result is the oracle's whatever the page size."""
+    import math
+    from types import SimpleNamespace
+    from oracle import attention as oa
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.mem_cache import MHATokenToKVPool, PagedTokenToKVPoolAllocator, ReqToTokenPool
+
+    ps, Hq, Hkv, D, dtype = 64, 8, 2, 64, torch.bfloat16
+    shape = H.TINY
+    runner = H.make_runner(shape, max_reqs=4, ctx=512, pool_tokens=64 * ps, dtype=dtype, device=DEV)
+    runner.token_to_kv_pool = MHATokenToKVPool(64 * ps, ps, dtype, Hkv, D, 1, DEV)
+    runner.req_to_token_pool = ReqToTokenPool(4, 512, DEV)
+    alloc = PagedTokenToKVPoolAllocator(64 * ps, ps, dtype, DEV, runner.token_to_kv_pool)
+    backend = MiAttnBackend(runner)
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    g = torch.Generator().manual_seed(4)
+    ext = [100, 64, 5]
+    B, E = len(ext), sum(ext)
+    pre = torch.zeros(B, dtype=torch.int64, device=DEV)
+    seq = torch.tensor(ext, dtype=torch.int64, device=DEV)
+    loc = alloc.alloc_extend(pre, seq, torch.full((B,), -1, dtype=torch.int64, device=DEV), E)
+    r2t = runner.req_to_token_pool.req_to_token
+    off = 0
+    for i, e in enumerate(ext):
+        r2t[i, :e] = loc[off: off + e].to(torch.int32); off += e
+    fb = SimpleNamespace(forward_mode=H.ForwardMode.EXTEND, batch_size=B, req_pool_indices=torch.arange(B, dtype=torch.int64, device=DEV),
+                         seq_lens=seq, seq_lens_sum=E, seq_lens_cpu=torch.tensor(ext),
+                         extend_prefix_lens=torch.zeros(B, dtype=torch.int32, device=DEV),
+                         extend_seq_lens=torch.tensor(ext, dtype=torch.int32, device=DEV),
+                         extend_prefix_lens_cpu=[0] * B, extend_seq_lens_cpu=ext, out_cache_loc=loc,
+                         req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                         attn_backend=backend, spec_info=None, positions=None)
+    q = torch.randn(E, Hq * D, generator=g).to(dtype)
+    k = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    backend.init_forward_metadata(fb)
+    o = backend.forward(q.to(DEV), k.to(DEV), v.to(DEV), layer, fb)
+    rows = 64 * ps + ps
+    kc, vc = torch.zeros(rows, Hkv, D, dtype=dtype), torch.zeros(rows, Hkv, D, dtype=dtype)
+    ref = oa.forward_extend(q, k, v, kc, vc, r2t.cpu(), fb.req_pool_indices.cpu(), seq.cpu(), fb.extend_prefix_lens.cpu(),
+                            fb.extend_seq_lens.cpu(), loc.cpu(), Hq, Hkv, D ** -0.5)
+    torch.testing.assert_close(o.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
+    # one decode step: request 1 (64 tokens = exactly one page) must open a new page, the others continue theirs
+    last = torch.stack([loc[99], loc[163], loc[168]])
+    new = alloc.alloc_decode(seq + 1, last)
+    assert int(new[0]) == int(last[0]) + 1 and int(new[1]) % ps == 0 and int(new[2]) == int(last[2]) + 1
+    for i in range(B):
+        r2t[i, ext[i]] = int(new[i])
+    fb.forward_mode = H.ForwardMode.DECODE
+    fb.seq_lens, fb.seq_lens_sum, fb.out_cache_loc = seq + 1, E + B, new
+    fb.seq_lens_cpu = torch.tensor([e + 1 for e in ext])
+    qd = torch.randn(B, Hq * D, generator=g).to(dtype)
+    kd = torch.randn(B, Hkv, D, generator=g).to(dtype)
+    vd = torch.randn(B, Hkv, D, generator=g).to(dtype)
+    backend.init_forward_metadata(fb)
+    od = backend.forward(qd.to(DEV), kd.to(DEV), vd.to(DEV), layer, fb)
+    refd = oa.forward_decode(qd, kd, vd, kc, vc, r2t.cpu(), fb.req_pool_indices.cpu(), fb.seq_lens.cpu(), new.cpu(), Hq, Hkv, D ** -0.5)
+    torch.testing.assert_close(od.cpu().float(), refd.float(), atol=2e-2, rtol=2e-2)
+    assert torch.equal(runner.token_to_kv_pool.k_buffer[0].cpu().view(torch.int16), kc.view(torch.int16))
