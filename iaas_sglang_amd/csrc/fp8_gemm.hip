@@ -537,6 +537,131 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
 }
 
 
+// LDS-DMA, scalar base + 32-bit lane offset; lds_dst wave-uniform (already an SGPR value)
+__device__ __forceinline__ void glds16_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp8_gemm_xd_kernel: the decode-shaped GEMM with a DEEP ring of 128-byte k-phases.
+//
+// What bounds the decode GEMM (tools/src/lds_fill.hip, a pure LDS-DMA skeleton of the gate_up shape, no MFMA):
+//   64-KiB stages (32 KiB shared x + 32 KiB private weights), issue -> wait -> barrier:   36 us  (= fp8_gemm_xs_kernel)
+//   the same with one stage in flight across the wait:                                     25 us
+//   32-KiB stages (one 128-byte k-phase), ring of 2 / 3 / 4 / 5:                     25.9 / 24.8 / 24.8 / 25.0 us
+// i.e. a stage takes ~2.2 us to land under full load wherever it comes from (L2 or HBM), and 160 KiB of LDS
+// cannot hold more than two 64-KiB stages.  So: 128-byte phases, x block [M x 128 B] + 8 wave-private weight
+// blocks [16 x 128 B] = 32 KiB per stage at M = 128, a ring of R = 4 stages, every stage requested 3 phases
+// ahead, counted vmcnt (2 phases in flight across the barrier), ONE barrier per phase.
+// LDS image as in fp8_gemm_tile_kernel: a DMA piece = 8 rows x 128 B (1 KiB, lane-linear), two consecutive rows
+// share one 256-byte LDS line, the 16-byte position inside the line is XOR-swizzled with (line & 15) on the
+// SOURCE side -> conflict-free ds_read_b128 fragments.  One v_mfma_scale_f32_16x16x128_f8f6f4 per (m tile, phase);
+// phases are walked in order, so results are bit-identical to fp8_gemm_xs_kernel (same fp32 accumulation order).
+template <typename OutT, int MT, int EPI, int R>
+__global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, float* __restrict__ slab, int S,
+                                                          int phases_per_wg /* 128-byte phases */, int force_slab,
+                                                          const SiluEpi epi) {
+  constexpr int NWV = 8, PB = 128, D = R - 1;
+  constexpr int ROWS = MT * 16;
+  constexpr int XBYTES = ROWS * PB, WBYTES = NWV * 16 * PB, STAGE = XBYTES + WBYTES;
+  constexpr int XP = ROWS / 8;                          // x DMA pieces (8 rows x 128 B) per phase
+  constexpr int XD = XP >= NWV ? XP / NWV : 1;          // per wave (small M: several waves fetch the same piece)
+  constexpr int E = XD + 2;                             // vmcnt entries per wave per phase
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t Ihalf = p.N / 2;
+  const int64_t c0 = ((int64_t)blockIdx.x * (NWV / 2) + (wave & (NWV / 2 - 1))) * 16;
+  const int64_t n0 = EPI ? (wave < NWV / 2 ? c0 : Ihalf + c0) : ((int64_t)blockIdx.x * NWV + wave) * 16;
+  const int sp = blockIdx.y;
+  const int64_t NPH = p.K / PB;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
+  const bool tile_ok = EPI ? c0 < Ihalf : n0 < p.N;
+  const uint32_t lds_base = lds_addr_of(smem);
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA geometry of a piece: lane L -> LDS byte L*16 of the piece; line pair l = 4*piece + (L >> 4), position
+  // P = L & 15 holds logical (row bit, slot) = P ^ (l & 15); 32-bit byte offsets from the scalar phase base
+  const int dline = lane >> 4, dpos = lane & 15;
+  uint32_t woff[2], xoff[XD], xlds[XD];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                         // this wave's own 16 weight rows = pieces 2*wave, 2*wave+1
+    const int line = (wave * 2 + i) * 4 + dline;
+    const int logical = dpos ^ (line & 15);
+    const int wrow = i * 8 + dline * 2 + (logical >> 3);                    // row inside the wave's 16
+    woff[i] = (uint32_t)(min(n0 + wrow, p.N - 1) * p.ldb + (logical & 7) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < XD; ++i) {
+    const int piece = (i * NWV + wave) % XP;
+    const int line = piece * 4 + dline;
+    const int logical = dpos ^ (line & 15);
+    const int row = line * 2 + (logical >> 3);
+    xoff[i] = (uint32_t)(min((int64_t)row, p.M - 1) * p.lda + (logical & 7) * 16);
+    xlds[i] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
+  }
+  const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_base + XBYTES + wave * 2 * 1024);
+
+  auto issue = [&](int64_t ph) __attribute__((always_inline)) {
+    const uint32_t st = (uint32_t)((ph - ph0) % R) * STAGE;
+    const uint8_t* xa = p.a + ph * PB;                   // wave-uniform: scalar arithmetic
+    const uint8_t* wa = p.b + ph * PB;
+#pragma unroll
+    for (int i = 0; i < XD; ++i) glds16_s(xoff[i], xa, xlds[i] + st);
+    glds16_s(woff[0], wa, wlds + st);
+    glds16_s(woff[1], wa, wlds + st + 1024);
+  };
+  // fragment (row, 16-byte slot) of a tile whose rows are 128 B: line pair = row >> 1, physical position
+  // ((row & 1) * 8 + slot) ^ (line & 15)
+  auto frag = [&](const char* base, int row, int slot) __attribute__((always_inline)) -> uint4 {
+    return *(const uint4*)(base + (row >> 1) * 256 + (((((row & 1) << 3) | slot) ^ ((row >> 1) & 15)) * 16));
+  };
+  // phases issued AFTER `ph` so far may stay in flight while we wait for `ph`: 0 .. D-1 of them
+  auto wait_phase = [&](int64_t ph) __attribute__((always_inline)) {
+    const int64_t after = min((int64_t)(D - 1), ph1 - 1 - ph);
+    if (D >= 4 && after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * E) : "memory");
+    else if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  static_assert(D == 3 || D == 4, "wait_phase enumerates up to 3 phases in flight");
+
+  if (ph0 < ph1) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (ph0 + d < ph1) issue(ph0 + d);
+    for (int64_t ph = ph0; ph < ph1; ++ph) {
+      wait_phase(ph);                                    // phase ph landed everywhere; everyone is done with ph-1
+      if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
+      if (tile_ok) {
+        const char* xb = smem + ((ph - ph0) % R) * STAGE;
+        const char* wb = xb + XBYTES;
+        const uint4 w0 = frag(wb, wave * 16 + r16, q), w1 = frag(wb, wave * 16 + r16, 4 + q);
+        const i32x8 wf = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const uint4 x0 = frag(xb, t * 16 + r16, q), x1 = frag(xb, t * 16 + r16, 4 + q);
+          const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+      }
+    }
+    __syncthreads();                                     // the epilogue may reuse LDS
+  }
+  xs_epilogue<OutT, MT, NWV, EPI>(p, slab, S, sp, force_slab, epi, acc, smem, n0, c0, Ihalf, tile_ok, lane, wave);
+}
+// LDS of the deep-ring kernel: 4 stages of (x [M x 128 B] + 8 x 2 KiB of weights); never below the EPI exchange buffer
+static size_t xd_lds(int mt, int r) { return (size_t)r * ((size_t)mt * 16 * 128 + 8 * 16 * 128); }
+
 // sum the S split-K slabs and apply the epilogue: one thread per 4 consecutive n
 template <typename OutT>
 __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p, const float* __restrict__ slab, int S) {
@@ -613,7 +738,10 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
   const int fs = partial ? 1 : 0;
   static const int split = xs_env("MI_GEMM_XS_SPLIT", 1);
-  if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
+  static const int deep = xs_env("MI_GEMM_XD", 1);
+  if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
+  else if (nw == 8 && deep) fp8_gemm_xd_kernel<OutT, MT, 0, 4><<<grid, 512, xd_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
+  else if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
   else if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
   else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw, fs);
   else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw, fs);
@@ -885,8 +1013,11 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
+  static const int deep = xs_env("MI_GEMM_XD", 1);
 #define LAUNCH_EPI(TT, MTV)                                                                                    \
-  fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
+  if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
+  else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
+  else fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
   if (dtype == MI_BF16) {
     if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else LAUNCH_EPI(bf16_t, 8);
   } else {
