@@ -895,6 +895,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   }
 }
 
+
 template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_t st) {
   const int mblocks = (int)cdiv64(p.M, 256), nblocks = (int)cdiv64(p.N, 256);
   fp8_gemm_tile_kernel<OutT><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks);
