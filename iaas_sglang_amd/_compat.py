@@ -17,8 +17,8 @@ from torch.nn import Parameter
 try:  # pragma: no cover - exercised only inside an SGLang install
     from sglang.srt.layers.attention.base_attn_backend import AttentionBackend
     from sglang.srt.layers.linear import LinearBase, LinearMethodBase, UnquantizedLinearMethod
-    from sglang.srt.layers.parameter import (GroupQuantScaleParameter, ModelWeightParameter,
-                                             PackedvLLMParameter, PerTensorScaleParameter)
+    from sglang.srt.layers.parameter import (ChannelQuantScaleParameter, GroupQuantScaleParameter,
+                                             ModelWeightParameter, PackedvLLMParameter, PerTensorScaleParameter)
     from sglang.srt.layers.quantization.base_config import QuantizationConfig, QuantizeMethodBase
     from sglang.srt.model_executor.forward_batch_info import ForwardMode
 
@@ -203,4 +203,7 @@ except Exception:  # ImportError or any of SGLang's own import-time failures
         pass
 
     class GroupQuantScaleParameter(_Param):
+        pass
+
+    class ChannelQuantScaleParameter(_Param):
         pass

@@ -3,10 +3,13 @@ AWQ int4, GPTQ int4.  Class names match the reference's (`Fp8LinearMethod`, `AWQ
 `GPTQLinearMethod`) so they are picked up by WEIGHT_LOADER_V2_SUPPORTED
 (python/sglang/srt/layers/linear.py:42-60)."""
 from .awq import AWQConfig, AWQLinearMethod
+from .compressed_tensors import CompressedTensorsConfig, CompressedTensorsLinearMethod, CompressedTensorsW8A8Fp8
 from .fp8 import Fp8Config, Fp8LinearMethod, apply_fp8_linear
 from .gptq import GPTQConfig, GPTQLinearMethod
 
-MI_QUANTIZATION_METHODS = {"fp8": Fp8Config, "awq": AWQConfig, "gptq": GPTQConfig}
+MI_QUANTIZATION_METHODS = {"fp8": Fp8Config, "awq": AWQConfig, "gptq": GPTQConfig,
+                           "compressed-tensors": CompressedTensorsConfig}
 
 __all__ = ["Fp8Config", "Fp8LinearMethod", "apply_fp8_linear", "AWQConfig", "AWQLinearMethod",
-           "GPTQConfig", "GPTQLinearMethod", "MI_QUANTIZATION_METHODS"]
+           "GPTQConfig", "GPTQLinearMethod", "CompressedTensorsConfig", "CompressedTensorsLinearMethod",
+           "CompressedTensorsW8A8Fp8", "MI_QUANTIZATION_METHODS"]

@@ -97,23 +97,11 @@ def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: to
     return out.view(*output_shape)
 
 
-class Fp8LinearMethod(LinearMethodBase):
-    """fp8.py:185-465 restricted to per-tensor scales."""
+class Fp8FusedDecodeMixin:
+    """Decode-shaped fused forms shared by the per-tensor FP8 linear methods (Fp8LinearMethod and the
+    compressed-tensors W8A8-FP8 scheme with tensor scales)."""
 
-    @staticmethod
-    def static_input_scale(layer: torch.nn.Module) -> Optional[torch.Tensor]:
-        """The calibrated per-tensor activation scale, if this layer has one: a producer kernel
-        (ops.rmsnorm_fp8 / silu_and_mul_fp8) may then emit the fp8 activation directly."""
-        s = getattr(layer, "input_scale", None)
-        return s if s is not None and s.numel() == 1 else None
-
-    def apply_prequantized(self, layer: torch.nn.Module, qx: torch.Tensor, out_dtype: torch.dtype,
-                           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`apply` minus the activation quantisation: qx is already fp8 with layer.input_scale."""
-        return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1),
-                            out_dtype, bias)
-
-    # ---- decode-shaped fused forms (SURVEY 8f rows 1-2): this linear + the op(s) that consume its output in
+    # this linear + the op(s) that consume its output in
     # a Llama decoder layer, one GEMM launch + one consumer launch, bit-identical to the unfused sequence.
     # All take an fp8 activation already quantised with layer.input_scale (static scheme).
     @staticmethod
@@ -139,6 +127,23 @@ class Fp8LinearMethod(LinearMethodBase):
         """fp8(silu(gate) * up) of linear(qx) = [gate | up], quantised with next_scale."""
         return ops.fp8_gemm_silu_mul(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),
                                      next_scale, act_dtype)
+
+
+class Fp8LinearMethod(Fp8FusedDecodeMixin, LinearMethodBase):
+    """fp8.py:185-465 restricted to per-tensor scales."""
+
+    @staticmethod
+    def static_input_scale(layer: torch.nn.Module) -> Optional[torch.Tensor]:
+        """The calibrated per-tensor activation scale, if this layer has one: a producer kernel
+        (ops.rmsnorm_fp8 / silu_and_mul_fp8) may then emit the fp8 activation directly."""
+        s = getattr(layer, "input_scale", None)
+        return s if s is not None and s.numel() == 1 else None
+
+    def apply_prequantized(self, layer: torch.nn.Module, qx: torch.Tensor, out_dtype: torch.dtype,
+                           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`apply` minus the activation quantisation: qx is already fp8 with layer.input_scale."""
+        return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1),
+                            out_dtype, bias)
 
     def __init__(self, quant_config: Fp8Config):
         self.quant_config = quant_config

@@ -19,7 +19,7 @@ def test_forward_mode_predicates_match_reference_table():
 
 
 def test_quant_registry_and_config_parsing():
-    assert set(MI_QUANTIZATION_METHODS) == {"fp8", "awq", "gptq"}
+    assert set(MI_QUANTIZATION_METHODS) == {"fp8", "awq", "gptq", "compressed-tensors"}
     c = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static", "ignored_layers": ["lm_head"]})
     assert c.is_checkpoint_fp8_serialized and c.activation_scheme == "static" and c.get_name() == "fp8"
     assert c.get_min_capability() <= 95 and torch.bfloat16 in c.get_supported_act_dtypes()
@@ -109,3 +109,45 @@ def test_ops_refuse_cpu_tensors():
     from iaas_sglang_amd._lib import MiHotpathError
     with pytest.raises(MiHotpathError):
         ops.kv_indptr(torch.tensor([1, 2, 3]))               # no CPU path exists in the product
+
+
+# ---- compressed-tensors (FP8 W8A8) config mirror: compressed_tensors.py:140-160,286-330,389-399,436-470
+def _ct_config(strategy="tensor", dynamic=False, act_strategy="tensor", wtype="float", ignore=("lm_head",)):
+    return {"quant_method": "compressed-tensors", "format": "float-quantized", "ignore": list(ignore),
+            "config_groups": {"group_0": {"targets": ["Linear"],
+                                          "weights": {"num_bits": 8, "type": wtype, "symmetric": True, "dynamic": False,
+                                                      "strategy": strategy},
+                                          "input_activations": {"num_bits": 8, "type": "float", "symmetric": True,
+                                                                "dynamic": dynamic, "strategy": act_strategy}}}}
+
+
+class _FakeLinear(torch.nn.Module):       # class name contains "Linear": matches the module-class target
+    output_partition_sizes = [8, 4]
+
+
+def test_compressed_tensors_fp8_scheme_selection_and_weights():
+    from iaas_sglang_amd.quantization import (CompressedTensorsConfig, CompressedTensorsLinearMethod,
+                                              CompressedTensorsW8A8Fp8)
+    from iaas_sglang_amd._compat import UnquantizedLinearMethod
+    cfg = CompressedTensorsConfig.from_config(_ct_config())
+    assert cfg.get_name() == "compressed_tensors" and cfg.ignore == ["lm_head"]
+    lin = _FakeLinear()
+    m = cfg.get_quant_method(lin, "model.layers.0.self_attn.qkv_proj")
+    assert isinstance(m, CompressedTensorsLinearMethod) and isinstance(lin.scheme, CompressedTensorsW8A8Fp8)
+    assert lin.scheme.strategy == "tensor" and lin.scheme.is_static_input_scheme
+    assert isinstance(cfg.get_quant_method(_FakeLinear(), "lm_head"), UnquantizedLinearMethod)      # ignore list
+    m.create_weights(lin, 16, [8, 4], 16, 12, torch.bfloat16, weight_loader=None)
+    assert lin.weight.dtype == torch.float8_e4m3fn and lin.weight.shape == (12, 16)
+    assert lin.weight_scale.shape == (2,) and lin.input_scale.shape == (2,) and lin.logical_widths == [8, 4]
+    # channel weights + dynamic per-token activations
+    cfg2 = CompressedTensorsConfig.from_config(_ct_config("channel", dynamic=True, act_strategy="token"))
+    lin2 = _FakeLinear()
+    m2 = cfg2.get_quant_method(lin2, "model.layers.0.mlp.down_proj")
+    assert lin2.scheme.strategy == "channel" and not lin2.scheme.is_static_input_scheme
+    m2.create_weights(lin2, 16, [12], 16, 12, torch.bfloat16, weight_loader=None)
+    assert lin2.weight_scale.shape == (12, 1) and not hasattr(lin2, "input_scale")
+    # schemes outside the hot path are refused loudly
+    with pytest.raises(NotImplementedError):
+        CompressedTensorsConfig.from_config(_ct_config(wtype="int")).get_quant_method(_FakeLinear(), "x.q_proj")
+    with pytest.raises(NotImplementedError):          # static per-token activations: not an fp8 w8a8 form
+        CompressedTensorsConfig.from_config(_ct_config(act_strategy="token")).get_quant_method(_FakeLinear(), "x.q_proj")

@@ -174,3 +174,54 @@ def test_input_to_float8_weight_mode_golden(golden_quant):
     q, inv = o_.fp8_quant_per_tensor(c["x"].to(DEV), weight_mode=True)
     assert torch.equal(q.cpu().view(torch.uint8), c["q"])
     assert torch.equal(inv.cpu().reshape(()), c["inv_scale"])
+
+
+# ---- compressed-tensors FP8 W8A8 checkpoints (the reference's own FP8 test model format)
+@pytest.mark.parametrize("strategy,dynamic", [("tensor", False), ("tensor", True), ("channel", True), ("channel", False)])
+def test_compressed_tensors_w8a8_fp8_linear_vs_oracle(strategy, dynamic):
+    """create_weights -> load a synthetic checkpoint (two fused shards, different per-shard scales) ->
+    process_weights_after_loading -> apply, against the oracle's restatement of the same steps."""
+    from iaas_sglang_amd.quantization import CompressedTensorsConfig
+    g = torch.Generator().manual_seed(3)
+    K, widths, M, dtype = 256, [192, 64], 37, torch.bfloat16
+    N = sum(widths)
+    cfg = CompressedTensorsConfig.from_config({
+        "format": "float-quantized", "ignore": [],
+        "config_groups": {"g": {"targets": ["Linear"],
+                                "weights": {"num_bits": 8, "type": "float", "symmetric": True, "dynamic": False, "strategy": strategy},
+                                "input_activations": {"num_bits": 8, "type": "float", "symmetric": True, "dynamic": dynamic,
+                                                      "strategy": "token" if dynamic else "tensor"}}}})
+
+    class FakeLinear(torch.nn.Module):
+        output_partition_sizes = widths
+    lin = FakeLinear()
+    method = cfg.get_quant_method(lin, "model.layers.0.self_attn.qkv_proj")
+    method.create_weights(lin, K, widths, K, N, dtype, weight_loader=None)
+    lin = lin.to(DEV)
+    w_fp = torch.randn(N, K, generator=g) * 0.05
+    if strategy == "tensor":
+        scales = torch.tensor([w_fp[:192].abs().max() / 448, w_fp[192:].abs().max() / 448])
+        wq = torch.cat([(w_fp[:192] / scales[0]), (w_fp[192:] / scales[1])]).clamp(-448, 448).to(torch.float8_e4m3fn)
+        lin.weight_scale.data.copy_(scales)
+    else:
+        scales = (w_fp.abs().amax(dim=1, keepdim=True) / 448)
+        wq = (w_fp / scales).clamp(-448, 448).to(torch.float8_e4m3fn)
+        lin.weight_scale.data.copy_(scales)
+    lin.weight.data.copy_(wq)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    in_scale = None
+    if not dynamic:
+        in_scale = (x.float().abs().max() / 448).reshape(1)
+        lin.input_scale.data.copy_(in_scale.expand(2))
+    method.process_weights_after_loading(lin)
+    y = method.apply(lin, x.to(DEV), None)
+    # oracle
+    if strategy == "tensor":
+        ws, w_o = oq.requantize_with_max_scale(wq, scales, widths)
+        ws = ws.reshape(1)
+    else:
+        ws, w_o = scales.reshape(-1), wq
+    ref = oq.fp8_linear(x, w_o.t(), ws, in_scale, per_token=dynamic)
+    torch.testing.assert_close(y.cpu().float(), ref.float(), atol=2e-2, rtol=2 ** -6)
+    if strategy == "tensor":       # the requantised weight bytes themselves are bit-exact
+        assert torch.equal(lin.weight.data.t().contiguous().cpu().view(torch.uint8), w_o.view(torch.uint8))
