@@ -150,6 +150,46 @@ def time_attention_kernel(stack, runner, backend, fb, reps):
     return e0.elapsed_time(e1) * 1e-3 / (reps * s.layers)
 
 
+def ragged_attention_leg(H, stack, runner, backend, B, S, dev, reps=2):
+    """Decode attention on the RAGGED variant of the workload (S_i ~ U[1, 2S], same total pool): the
+    backend's ragged plan (fixed 512-key splits + a longest-first launch list) against the same layer pools."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(1, 2 * S + 1, (B,), generator=g)
+    while int(lens.sum()) > B * S:
+        lens = (lens.float() * 0.98).long().clamp(min=1)
+    fb = H.make_decode_batch(runner, backend, B, 0, dev, seed=1, ragged=lens)
+    backend.init_forward_metadata(fb)
+    md = backend.forward_metadata
+    s = stack.shape
+    q = torch.randn(B, stack.Hq, s.head_dim, device=dev, dtype=torch.float32).to(stack.dtype)
+    o = torch.empty_like(q)
+    pool = runner.token_to_kv_pool
+    if pool.get_key_buffer(0).element_size() == 1:
+        return None
+
+    def one_pass():
+        for li in range(s.layers):
+            ops.decode_attention(q, pool.get_key_buffer(li), pool.get_value_buffer(li), o, md.kv_indptr, md.kv_indices,
+                                 s.head_dim ** -0.5, 0.0, md.num_kv_splits, md.workspace, split_chunk=md.split_chunk,
+                                 work=md.work)
+    one_pass()
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        one_pass()
+    e1.record(stream)
+    e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / (reps * s.layers)
+    tot = int(lens.sum())
+    nbytes = 2 * tot * stack.Hkv * s.head_dim * 2 + 2 * B * stack.Hq * s.head_dim * 2 + 4 * tot
+    return {"keys": tot, "max_len": int(lens.max()), "min_len": int(lens.min()), "avg_launch_us": round(t * 1e6, 2),
+            "achieved_GBps": round(nbytes / t / 1e9, 1), "kv_splits": md.num_kv_splits, "split_chunk": md.split_chunk,
+            "work_items": None if md.work is None else int(md.work.shape[0])}
+
+
 def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, reps=2):
     """Prefill TFLOP/s (the other half of BASELINE.json's metric) on a bounded sample: one EXTEND batch
     of `nseq` sequences x S new tokens (no cached prefix), whole layer stack, eager launches."""
@@ -352,6 +392,12 @@ def main():
             prefill = prefill_leg(H, stack, runner, backend, shape, a.prefill_batch, S, dev, world)
         except Exception as e:   # the decode number must not be lost to a prefill-side problem
             prefill = {"error": f"{type(e).__name__}: {e}"}
+    ragged = None
+    if world == 1:
+        try:
+            ragged = ragged_attention_leg(H, stack, runner, backend, B, S, dev)
+        except Exception as e:   # informational only
+            ragged = {"error": f"{type(e).__name__}: {e}"}
     result = {
         "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)" + (" [variant: fp8 KV cache]" if kv8 else ""),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -365,6 +411,7 @@ def main():
                    "all_reduce": None if tp == 1 else ("native-xgmi" if custom_ar is not None else "rccl"),
                    "kv_splits": kv_splits},
         "prefill": prefill,
+        "ragged_decode_attention": ragged,
         "step_hbm_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"kernel": "decode_attn_kernel (+ split merge)", "bound": "hbm", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -28,6 +28,7 @@ class ForwardMetadata:
     num_kv_splits: int
     workspace: Optional[torch.Tensor]
     split_chunk: int = 0                            # keys per split (0: seq_len / num_kv_splits per request)
+    work: Optional[torch.Tensor] = None             # ragged batches: (request, split) launch list, longest first
     custom_mask: Optional[torch.Tensor] = None      # TARGET_VERIFY: flat tree mask (triton_backend.py:253-260)
     mask_indptr: Optional[torch.Tensor] = None
 
@@ -82,21 +83,33 @@ class MiAttnBackend(AttentionBackend):
         return best
 
     def _choose_split_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None):
-        """(num_kv_splits, split_chunk).  Uniform batches (or no host-side lengths): _choose_splits.  RAGGED batches
-        (longest request > 1.5x the mean): the longest request sets the kernel time, so split by ITS length
-        (~512 keys per split).  Measured at B=128, S_i ~ U[1,4096] (257 k keys): 2 splits 280 us, 6-8 splits
-        245-270 us, vs 183 us for the uniform batch of the same size.  Fixed-size splits (the kernel's split_chunk)
-        were measured too -- 260-300 us for chunks of 256..1024 keys: what is lost is the last partial round of
-        workgroups, not the balance inside a round, so the plan keeps chunk 0 (a persistent work-queue form is the
-        real fix and is future work)."""
+        """(num_kv_splits, split_chunk, work list).  Uniform batches (or no host-side lengths, or inside a graph
+        capture): _choose_splits, no chunk, no list.  RAGGED batches (longest request > 1.5x the mean): fixed-size
+        splits of `chunk` keys and a host-built launch list of the non-empty (request, split) pairs -- all full
+        chunks first, then the remainders by decreasing length, so the last round of workgroups is filled with the
+        short pieces (longest-processing-time-first packing).  Measured at B=128, S_i ~ U[1,4096] (257 k keys):
+        per-request S/2 splits 280 us, S/8 245-270 us, fixed chunks in grid order 260-300 us, this list: see
+        DESIGN.md section 3.1; the uniform batch of the same size takes 183 us."""
         splits = self._choose_splits(bs, seq_lens_sum)
-        if seq_lens_cpu is None or bs <= 1:
-            return splits, 0
-        lens = torch.as_tensor(seq_lens_cpu)[:bs]
+        if seq_lens_cpu is None or bs <= 1 or torch.cuda.is_current_stream_capturing():
+            return splits, 0, None
+        lens = torch.as_tensor(seq_lens_cpu)[:bs].to(torch.int64)
         mx, avg = int(lens.max()), max(seq_lens_sum // max(bs, 1), 1)
-        if 2 * mx > 3 * avg and mx > 512:
-            splits = int(min(self.max_kv_splits, max(splits, -(-mx // 512))))
-        return splits, 0
+        if not (2 * mx > 3 * avg and mx > 512):
+            return splits, 0, None
+        chunk = max(getattr(self, "min_split_chunk", 512), -(-mx // self.max_kv_splits))
+        chunk = (chunk + 15) // 16 * 16
+        nsplit = -(-mx // chunk)
+        full, rem = lens // chunk, lens % chunk
+        # full chunks: split index outermost so that neighbouring workgroups are different requests (XCD spread)
+        fs = torch.arange(int(full.max()) if bs else 0).view(-1, 1)
+        mask = fs < full.view(1, -1)
+        b_idx = torch.arange(bs).view(1, -1).expand_as(mask)[mask]
+        s_idx = fs.expand_as(mask)[mask]
+        order = torch.argsort(rem, descending=True)
+        order = order[rem[order] > 0]
+        work = torch.stack([torch.cat([b_idx, order]), torch.cat([s_idx, full[order]])], dim=1).to(torch.int32)
+        return nsplit, chunk, work.contiguous().to(self.device, non_blocking=True)
 
     def _workspace(self, bs: int, splits: int) -> Optional[torch.Tensor]:
         n = ops.decode_workspace_numel(bs, self.num_head, self.v_head_dim, splits)
@@ -135,10 +148,10 @@ class MiAttnBackend(AttentionBackend):
             kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum), 1), dtype=torch.int32, device=self.device)
             ops.kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
                            kv_indices)
-            splits, chunk = self._choose_split_plan(bs, int(forward_batch.seq_lens_sum),
-                                                    getattr(forward_batch, "seq_lens_cpu", None))
+            splits, chunk, work = self._choose_split_plan(bs, int(forward_batch.seq_lens_sum),
+                                                          getattr(forward_batch, "seq_lens_cpu", None))
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, None, None, splits,
-                                                    self._workspace(bs, splits), split_chunk=chunk)
+                                                    self._workspace(bs, splits), split_chunk=chunk, work=work)
         else:
             # extend / mixed: kv_indices cover the cached PREFIX only (triton_backend.py:302-321); the
             # host-side length lists avoid the reference's .item() syncs (:288,:320)
@@ -229,25 +242,25 @@ class MiAttnBackend(AttentionBackend):
                 o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
                 ops.decode_attention_fp8kv(q3, k_buf, v_buf, md.kv_indptr, md.kv_indices, layer.scaling, ks, vs, cap,
                                            md.num_kv_splits, md.workspace, o_fp8=o8, o_scale=fp8_out_scale,
-                                           split_chunk=md.split_chunk)
+                                           split_chunk=md.split_chunk, work=md.work)
                 return o8
             o = q.new_empty(q.shape)
             ops.decode_attention_fp8kv(q3, k_buf, v_buf, md.kv_indptr, md.kv_indices, layer.scaling, ks, vs, cap,
                                        md.num_kv_splits, md.workspace, o=o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
-                                       split_chunk=md.split_chunk)
+                                       split_chunk=md.split_chunk, work=md.work)
             return o
         if fp8_out_scale is not None:
             o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
             ops.decode_attention_fp8out(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf, o8,
                                         fp8_out_scale, md.kv_indptr, md.kv_indices, layer.scaling,
                                         getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace,
-                                        split_chunk=md.split_chunk)
+                                        split_chunk=md.split_chunk, work=md.work)
             return o8
         o = q.new_empty(q.shape)
         ops.decode_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf,
                              o.view(-1, layer.tp_q_head_num, layer.v_head_dim), md.kv_indptr, md.kv_indices,
                              layer.scaling, getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace,
-                             split_chunk=md.split_chunk)
+                             split_chunk=md.split_chunk, work=md.work)
         return o
 
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):

@@ -29,6 +29,8 @@ struct DecodeParams {
   float* ws_o;   // [B][Hq][splits][D]
   float* ws_ml;  // [B][Hq][splits][2]
   int32_t num_q_heads, num_kv_heads, group, num_splits;
+  const int32_t* work;   // optional work list [num_work][2] = (request, split): launch order and non-empty splits only
+  int32_t num_work;
   int32_t split_chunk;   // > 0: every split covers this many keys (multiple of 16) unless the request needs more
   int64_t stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot;
   float scale_log2;  // sm_scale * log2(e)   (logit_cap == 0)
@@ -113,9 +115,11 @@ void decode_attn_kernel(const DecodeParams p) {
   // request index fastest: consecutive workgroups (which the hardware deals round-robin to the 8 XCDs) are
   // different requests of the SAME split, so the non-empty splits of a ragged batch spread over all XCDs
   // (with the split index fastest, fixed-size splits s = 0..k of every request landed on XCDs 0..k only)
-  const int b = blockIdx.x;
+  // work list (ragged batches): the host hands out only non-empty (request, split) pairs, full chunks first and the
+  // short remainders last, so the tail of the launch is filled with small pieces (longest-first packing)
+  const int b = p.work ? p.work[2 * blockIdx.x] : (int)blockIdx.x;
   const int hk = blockIdx.y * W + wave;
-  const int s = blockIdx.z;
+  const int s = p.work ? p.work[2 * blockIdx.x + 1] : (int)blockIdx.z;
   if (hk >= p.num_kv_heads) return;
   const int group = p.group;
   const int nsplit = p.num_splits;
@@ -367,19 +371,30 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
                                                            int64_t n_bh, int32_t num_q_heads,
                                                            int32_t nsplit, int64_t stride_o_tok,
                                                            uint8_t* __restrict__ o_q, const float* __restrict__ o_qscale,
-                                                           float out_scale) {
+                                                           float out_scale, const int32_t* __restrict__ kv_indptr,
+                                                           int32_t split_chunk) {
   constexpr int EPL = D / 64 > 0 ? D / 64 : 1;  // elements per lane
   const int lane = threadIdx.x & 63;
   const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bh >= n_bh) return;
   const float* ml = ws_ml + bh * nsplit * 2;
+  // splits that exist for this request (the same rule as the split kernel): with a work list the others were never
+  // launched and their workspace entries are undefined
+  int nvalid;
+  {
+    const int64_t bq = bh / num_q_heads;
+    const int32_t S = kv_indptr[bq + 1] - kv_indptr[bq];
+    int32_t per = (S + nsplit - 1) / nsplit;
+    per = max((per + 15) & ~15, split_chunk);
+    nvalid = per > 0 ? min(nsplit, (S + per - 1) / per) : 0;
+  }
   float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ml[2 * s]);
+  for (int s = 0; s < nvalid; ++s) M = fmaxf(M, ml[2 * s]);
   float L = 0.f, acc[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
   const bool active = lane * EPL < D;
-  for (int s = 0; s < nsplit; ++s) {
+  for (int s = 0; s < nvalid; ++s) {
     const float ls = ml[2 * s + 1];
     if (!(ls > 0.f)) continue;  // empty split: its ws_o slice was never written
     const float w = fast_exp2(ml[2 * s] - M);
@@ -427,7 +442,7 @@ static int env_int(const char* name, int dflt) {
 
 template <typename T, int D, int G, int W, bool KV8>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
-  dim3 grid((unsigned)batch, (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)p.num_splits);
+  dim3 grid((unsigned)(p.work ? p.num_work : batch), (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)(p.work ? 1 : p.num_splits));
   decode_attn_kernel<T, D, G, W, KV8><<<grid, W * 64, 0, st>>>(p);
 }
 
@@ -460,8 +475,9 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
                             int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                             int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                             int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                            float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream, void* o_fp8,
-                            const float* o_scale, bool kv8 = false, float k_scale = 1.f, float v_scale = 1.f) {
+                            float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work,
+                            int dtype, void* stream, void* o_fp8, const float* o_scale, bool kv8 = false,
+                            float k_scale = 1.f, float v_scale = 1.f) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
   MI_CHECK_ARG(q && k_buf && v_buf && (o || o_fp8) && kv_indptr && kv_indices);
@@ -490,6 +506,8 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   p.num_q_heads = (int32_t)num_q_heads; p.num_kv_heads = (int32_t)num_kv_heads;
   p.group = (int32_t)(num_q_heads / num_kv_heads); p.num_splits = (int32_t)num_splits;
   p.split_chunk = (int32_t)split_chunk;
+  MI_CHECK_ARG(!work || (num_work > 0 && num_work <= 0x7fffffff && num_splits > 1 && split_chunk > 0));
+  p.work = work; p.num_work = (int32_t)num_work;
   p.stride_q_tok = stride_q_tok; p.stride_o_tok = stride_o_tok;
   p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
   // fp8 KV: logits = sm_scale * k_scale * (q . k8), out = v_scale * softmax . v8
@@ -514,14 +532,14 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
     const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
     if (dtype == MI_BF16) {
       if (head_dim == 128)
-        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
+        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
       else
-        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
+        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
     } else {
       if (head_dim == 128)
-        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
+        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
       else
-        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale);
+        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
     }
     MI_CHECK_LAUNCH();
   }
@@ -533,10 +551,10 @@ extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_bu
                               int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                               int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                               int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                              float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
+                              float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream) {
   MI_CHECK_ARG(o != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
                           stream, nullptr, nullptr);
 }
 
@@ -545,10 +563,11 @@ extern "C" int mi_decode_attn_fp8out(const void* q, const void* k_buf, const voi
                                      const int32_t* kv_indices, void* workspace, int64_t batch, int64_t num_q_heads,
                                      int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                                      int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
-                                     int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
+                                     int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype,
+                                     void* stream) {
   MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
                           stream, o_fp8, o_scale);
 }
 
@@ -557,8 +576,8 @@ extern "C" int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void
                                     const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace, int64_t batch,
                                     int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                                     int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                                    float logit_cap, int64_t num_splits, int64_t split_chunk, int dtype, void* stream) {
+                                    float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream) {
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
                           stream, o_fp8, o_scale, true, k_scale, v_scale);
 }

@@ -128,10 +128,19 @@ def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_sp
     return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4
 
 
+def _work_args(work: Optional[torch.Tensor]):
+    """(pointer, count) of an optional decode work list: int32 [n, 2] = (request, split), contiguous, on the device."""
+    if work is None:
+        return None, 0
+    assert work.dtype == torch.int32 and work.dim() == 2 and work.shape[1] == 2 and work.is_contiguous() and work.is_cuda
+    return _ptr(work), work.shape[0]
+
+
 def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o: torch.Tensor,
                      kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, sm_scale: float,
                      logit_cap: float = 0.0, num_splits: int = 1,
-                     workspace: Optional[torch.Tensor] = None, split_chunk: int = 0) -> torch.Tensor:
+                     workspace: Optional[torch.Tensor] = None, split_chunk: int = 0,
+                     work: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q,o [B,Hq,D]; k_buf,v_buf [slots,Hkv,D]; split-KV token attention (split_chunk: keys per split, 0 = S/splits)."""
     B, Hq, D = q.shape
     Hkv = k_buf.shape[1]
@@ -145,7 +154,7 @@ def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, 
     check(lib.mi_decode_attn(_ptr(q), _ptr(k_buf), _ptr(v_buf), _ptr(o), _ptr(kv_indptr_t), _ptr(kv_indices_t),
                              _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0), o.stride(0),
                              k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap),
-                             int(num_splits), int(split_chunk), _dt(q), _stream()), "mi_decode_attn")
+                             int(num_splits), int(split_chunk), *_work_args(work), _dt(q), _stream()), "mi_decode_attn")
     return o
 
 
@@ -408,7 +417,7 @@ def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.T
                             o_scale: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,
                             sm_scale: float, logit_cap: float = 0.0, num_splits: int = 1,
                             workspace: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None,
-                            split_chunk: int = 0) -> torch.Tensor:
+                            split_chunk: int = 0, work: Optional[torch.Tensor] = None) -> torch.Tensor:
     """decode_attention whose output stage also quantises for the following static-scale FP8 linear:
     o_fp8 [B, Hq*D] = quant(o, o_scale), bit-identical to decode_attention + fp8_quant_per_tensor(scale)."""
     B, Hq, D = q.shape
@@ -427,8 +436,8 @@ def decode_attention_fp8out(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.T
                                     _ptr(kv_indptr_t), _ptr(kv_indices_t),
                                     _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
                                     o.stride(0) if o is not None else Hq * D, k_buf.stride(0), v_buf.stride(0),
-                                    float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), _dt(q), _stream()),
-          "mi_decode_attn_fp8out")
+                                    float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), *_work_args(work),
+                                    _dt(q), _stream()), "mi_decode_attn_fp8out")
     return o_fp8
 
 
@@ -436,7 +445,8 @@ def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.
                            kv_indices_t: torch.Tensor, sm_scale: float, k_scale: float = 1.0, v_scale: float = 1.0,
                            logit_cap: float = 0.0, num_splits: int = 1, workspace: Optional[torch.Tensor] = None,
                            o: Optional[torch.Tensor] = None, o_fp8: Optional[torch.Tensor] = None,
-                           o_scale: Optional[torch.Tensor] = None, split_chunk: int = 0):
+                           o_scale: Optional[torch.Tensor] = None, split_chunk: int = 0,
+                           work: Optional[torch.Tensor] = None):
     """Decode attention over an fp8 (e4m3fn / uint8 storage) KV pool [slots, Hkv, 128]."""
     B, Hq, D = q.shape
     Hkv = k_buf8.shape[1]
@@ -455,8 +465,8 @@ def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.
                                    float(k_scale), float(v_scale), _ptr(kv_indptr_t), _ptr(kv_indices_t),
                                    _ptr(workspace) if num_splits > 1 else None, B, Hq, Hkv, D, q.stride(0),
                                    o.stride(0) if o is not None else Hq * D, k_buf8.stride(0), v_buf8.stride(0),
-                                   float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), _dt(q), _stream()),
-          "mi_decode_attn_fp8kv")
+                                   float(sm_scale), float(logit_cap), int(num_splits), int(split_chunk), *_work_args(work),
+                                   _dt(q), _stream()), "mi_decode_attn_fp8kv")
     return o if o is not None else o_fp8
 
 

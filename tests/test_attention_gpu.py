@@ -544,3 +544,35 @@ def test_decode_fixed_chunk_splits_on_ragged_batch(chunk, splits):
     ops.decode_attention(q.to(DEV), kb.to(DEV), vb.to(DEV), o, indptr, idx, D ** -0.5, 0.0, splits, ws, split_chunk=chunk)
     torch.cuda.synchronize()
     torch.testing.assert_close(o.cpu().float(), ref, atol=2e-3, rtol=2 ** -7)
+
+
+def test_backend_ragged_decode_uses_work_list_and_matches_oracle():
+    """A ragged decode batch through MiAttnBackend: the plan is fixed chunks + a launch list (longest first); the
+    result is the oracle's, and the KV write still happens."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype = H.LLAMA3_8B, torch.bfloat16
+    Hq, Hkv, D = 32, 8, 128
+    lens = [1500, 40, 700, 513, 90, 1024, 2, 333]
+    runner = H.make_runner(shape, max_reqs=8, ctx=2048, pool_tokens=sum(lens) + 8, dtype=dtype, device=DEV, fill_kv=True)
+    runner.token_to_kv_pool = H.make_kv_pool(sum(lens) + 8, 1, Hkv, D, dtype, DEV, fill_random=True)
+    backend = MiAttnBackend(runner)
+    fb = H.make_decode_batch(runner, backend, len(lens), 0, DEV, seed=2, ragged=torch.tensor(lens))
+    backend.init_forward_metadata(fb)
+    md = backend.forward_metadata
+    assert md.work is not None and md.split_chunk == 512 and md.num_kv_splits == 3
+    assert md.work.shape[0] == sum(-(-L // 512) for L in lens)
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(len(lens), Hq * D, generator=g).to(dtype)
+    k = torch.randn(len(lens), Hkv, D, generator=g).to(dtype)
+    v = torch.randn(len(lens), Hkv, D, generator=g).to(dtype)
+    pool = runner.token_to_kv_pool
+    kc, vc = pool.k_buffer[0].cpu().clone(), pool.v_buffer[0].cpu().clone()
+    o = backend.forward(q.to(DEV), k.to(DEV), v.to(DEV), layer, fb)
+    ref = oa.forward_decode(q, k, v, kc, vc, runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
+                            fb.seq_lens.cpu(), fb.out_cache_loc.cpu(), Hq, Hkv, D ** -0.5)
+    torch.testing.assert_close(o.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
+    oa_f = oa.decode_fp32(q.view(-1, Hq, D), kc, vc, runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
+                          fb.seq_lens.cpu(), scaling=D ** -0.5)
+    torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), oa_f, atol=4e-3, rtol=2 ** -7)

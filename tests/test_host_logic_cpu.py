@@ -80,12 +80,21 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     assert be._choose_splits(1, 100000) == 8                 # capped by --triton-attention-num-kv-splits
     assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
     # ragged batches are split by their longest request; uniform ones by the whole-rounds model
-    assert be._choose_split_plan(128, 128 * 2048, torch.full((128,), 2048)) == (2, 0)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    assert be._choose_split_plan(128, 128 * 2048, torch.full((128,), 2048)) == (2, 0, None)
     g = torch.Generator().manual_seed(0)
     lens = torch.randint(1, 4097, (128,), generator=g)
-    ns, chunk = be._choose_split_plan(128, int(lens.sum()), lens)
-    assert chunk == 0 and ns == 8                                        # ragged: split by the longest request
-    assert be._choose_split_plan(128, 128 * 2048, None) == (2, 0)        # no host-side lengths (graph replay)
+    ns, chunk, work = be._choose_split_plan(128, int(lens.sum()), lens)
+    assert chunk == 512 and ns == -(-int(lens.max()) // 512) and work.dtype == torch.int32 and work.shape[1] == 2
+    # the list holds every non-empty (request, split) exactly once: full chunks first, remainders longest first
+    want = {(b, s) for b in range(128) for s in range(-(-int(lens[b]) // 512))}
+    got = [tuple(r) for r in work.tolist()]
+    assert len(got) == len(want) and set(got) == want
+    nfull = int((lens // 512).sum())
+    assert all(s < int(lens[b]) // 512 for b, s in got[:nfull])
+    tail = [int(lens[b]) % 512 for b, s in got[nfull:]]
+    assert tail == sorted(tail, reverse=True) and all(t > 0 for t in tail)
+    assert be._choose_split_plan(128, 128 * 2048, None) == (2, 0, None)   # no host-side lengths (graph replay)
     fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.DRAFT_EXTEND, spec_info=None)
     with pytest.raises(NotImplementedError):
         be.init_forward_metadata(fb)                          # draft-side speculative modes: out of scope, loud

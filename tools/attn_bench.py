@@ -33,17 +33,28 @@ indptr = ops.kv_indptr(sl)
 tot = int(sl.sum())
 abytes = 2 * tot * Hkv * D * 2 + 2 * B * Hq * D * 2 + 4 * tot
 print(f"tokens {tot} max {int(sl.max())} min {int(sl.min())}", flush=True)
+CHUNK = int(os.environ.get('CHUNK', '0'))
+WORK = None
+if os.environ.get('WORKLIST', '0') == '1':      # the backend's ragged plan: fixed chunks + longest-first launch list
+    from types import SimpleNamespace
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    be = MiAttnBackend.__new__(MiAttnBackend)
+    be.num_kv_head, be.cu_count, be.max_kv_splits, be.device = Hkv, ops.cu_count(), int(os.environ.get('MAXS', '8')), dev
+    be.min_split_chunk = int(os.environ.get('FLOOR', '512'))
+    ns_, CHUNK, WORK = be._choose_split_plan(B, tot, sl.cpu())
+    os.environ['SPLITS'] = str(ns_)
+    print(f'work list: {0 if WORK is None else WORK.shape[0]} entries, chunk {CHUNK}, splits {ns_}', flush=True)
 for ns in [int(x) for x in os.environ.get("SPLITS", "1,2,4,8").split(",")]:
     ws = torch.empty(max(1, ops.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=dev)
     for k, v in pools:
-        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=int(os.environ.get('CHUNK', '0')))
+        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=CHUNK, work=WORK)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
     e0.record()
     for _ in range(reps):
         for k, v in pools:
-            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=int(os.environ.get('CHUNK', '0')))
+            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=CHUNK, work=WORK)
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * npool)
     print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} contig={int(contig)} splits={ns} W={os.environ.get('MI_DECODE_W','auto')}: "
