@@ -312,7 +312,7 @@ def main():
         os.environ["MI_ATTN_MAX_KV_SPLITS"] = str(a.splits)
 
     kv8 = a.kv_dtype == "fp8"
-    runner = H.make_runner(shape, max_reqs=B, ctx=S + 8, pool_tokens=B * S, dtype=dtype, device=dev, tp=tp,
+    runner = H.make_runner(shape, max_reqs=B, ctx=2 * S + 8, pool_tokens=B * S, dtype=dtype, device=dev, tp=tp,
                            fill_kv=True, seed=rank, max_kv_splits=a.splits or 8,
                            kv_dtype=torch.float8_e4m3fn if kv8 else None)
     backend = MiAttnBackend(runner)
