@@ -30,11 +30,11 @@ SIGNATURES = {
     "mi_alloc_decode": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                              _f, _f, _i64, _i64, _p, _i64, _int, _p]),
+                              _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_decode_attn_fp8out": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                                     _f, _f, _i64, _i64, _p, _i64, _int, _p]),
+                                     _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_decode_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,
-                                    _i64, _i64, _f, _f, _i64, _i64, _p, _i64, _int, _p]),
+                                    _i64, _i64, _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -91,8 +91,8 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name} (ABI mismatch with include/mi_hotpath.h)")
         fn.restype = res
         fn.argtypes = args
-    if lib.mi_abi_version() != 3:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != 3")
+    if lib.mi_abi_version() != 4:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != 4")
     return lib
 
 

@@ -82,21 +82,25 @@ class MiAttnBackend(AttentionBackend):
                 best, best_cost = s, cost
         return best
 
-    def _choose_split_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None):
-        """(num_kv_splits, split_chunk, work list).  Uniform batches (or no host-side lengths, or inside a graph
-        capture): _choose_splits, no chunk, no list.  RAGGED batches (longest request > 1.5x the mean): fixed-size
-        splits of `chunk` keys and a host-built launch list of the non-empty (request, split) pairs -- all full
-        chunks first, then the remainders by decreasing length, so the last round of workgroups is filled with the
-        short pieces (longest-processing-time-first packing).  Measured at B=128, S_i ~ U[1,4096] (257 k keys):
-        per-request S/2 splits 280 us, S/8 245-270 us, fixed chunks in grid order 260-300 us, this list: see
+    def _plan_on_host(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None, force_list: bool = False):
+        """(num_kv_splits, split_chunk, host work list or None).  Uniform batches: _choose_splits, no chunk, no list
+        (with `force_list`: the full (request, split) grid, split index outermost).  RAGGED batches (longest request
+        > 1.5x the mean): fixed-size splits of `chunk` keys and a launch list of the non-empty (request, split) pairs
+        -- all full chunks first, then the remainders by decreasing length, so the last round of workgroups is filled
+        with the short pieces (longest-processing-time-first packing).  Measured at B=128, S_i ~ U[1,4096] (257 k
+        keys): per-request S/2 splits 280 us, S/8 245-270 us, fixed chunks in grid order 260-300 us, this list: see
         DESIGN.md section 3.1; the uniform batch of the same size takes 183 us."""
         splits = self._choose_splits(bs, seq_lens_sum)
-        if seq_lens_cpu is None or bs <= 1 or torch.cuda.is_current_stream_capturing():
-            return splits, 0, None
-        lens = torch.as_tensor(seq_lens_cpu)[:bs].to(torch.int64)
-        mx, avg = int(lens.max()), max(seq_lens_sum // max(bs, 1), 1)
-        if not (2 * mx > 3 * avg and mx > 512):
-            return splits, 0, None
+        ragged = False
+        if seq_lens_cpu is not None and bs > 1:
+            lens = torch.as_tensor(seq_lens_cpu)[:bs].to(torch.int64)
+            mx, avg = int(lens.max()), max(seq_lens_sum // max(bs, 1), 1)
+            ragged = 2 * mx > 3 * avg and mx > 512
+        if not ragged:
+            if not force_list:
+                return splits, 0, None
+            work = torch.stack([torch.arange(bs).repeat(splits), torch.arange(splits).repeat_interleave(bs)], dim=1)
+            return splits, 0, work.to(torch.int32)
         chunk = max(getattr(self, "min_split_chunk", 512), -(-mx // self.max_kv_splits))
         chunk = (chunk + 15) // 16 * 16
         nsplit = -(-mx // chunk)
@@ -109,7 +113,14 @@ class MiAttnBackend(AttentionBackend):
         order = torch.argsort(rem, descending=True)
         order = order[rem[order] > 0]
         work = torch.stack([torch.cat([b_idx, order]), torch.cat([s_idx, full[order]])], dim=1).to(torch.int32)
-        return nsplit, chunk, work.contiguous().to(self.device, non_blocking=True)
+        return nsplit, chunk, work.contiguous()
+
+    def _choose_split_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None):
+        """(num_kv_splits, split_chunk, device work list or None) of an eager decode step -- see _plan_on_host."""
+        if torch.cuda.is_current_stream_capturing():
+            seq_lens_cpu = None
+        splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu)
+        return splits, chunk, (work.to(self.device, non_blocking=True) if work is not None else None)
 
     def _workspace(self, bs: int, splits: int) -> Optional[torch.Tensor]:
         n = ops.decode_workspace_numel(bs, self.num_head, self.v_head_dim, splits)
@@ -167,13 +178,48 @@ class MiAttnBackend(AttentionBackend):
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, 1, None)
 
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
-        """Preallocate everything replay touches (triton_backend.py:338-388)."""
+        """Preallocate everything replay touches (triton_backend.py:338-388).  Beyond the reference's buffers: the
+        decode PLAN.  A captured launch bakes its grid and scalar arguments in, so the captured decode kernels take
+        the split count, the split size and the (request, split) launch list from a device buffer instead
+        (mi_decode_attn's `plan`), which replay rewrites from the host-side lengths with one small async copy."""
         self.cuda_graph_kv_indices = (kv_indices_buf if kv_indices_buf is not None else
                                       torch.zeros(max_num_tokens * self.max_context_len, dtype=torch.int32,
                                                   device=self.device))
         n = ops.decode_workspace_numel(max_num_tokens, self.num_head, self.v_head_dim, self.max_kv_splits)
         self.cuda_graph_workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
-        self.cuda_graph_splits = {}
+        cap = max_num_tokens * self.max_kv_splits
+        self.cuda_graph_plan_buf = torch.zeros(4 + 2 * cap, dtype=torch.int32, device=self.device)
+        pin = torch.device(self.device).type == "cuda"
+        self._plan_stage = [torch.zeros(4 + 2 * cap, dtype=torch.int32, pin_memory=pin) for _ in range(4)]
+        self._plan_stage_ev = [None] * len(self._plan_stage)
+        self._plan_stage_i = 0
+
+    def _write_graph_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu):
+        """Plan this replay on the host and ship {num_work, num_splits, split_chunk | work list} to the device buffer
+        the captured kernels read.  The pinned staging buffers rotate (an event guards reuse), so the copy is
+        asynchronous and the host never waits unless it runs four steps ahead of the device."""
+        splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu, force_list=True)
+        n = work.shape[0]
+        assert splits <= self.max_kv_splits and n <= bs * self.max_kv_splits
+        i = self._plan_stage_i
+        self._plan_stage_i = (i + 1) % len(self._plan_stage)
+        stage, ev = self._plan_stage[i], self._plan_stage_ev[i]
+        if ev is not None:
+            ev.synchronize()
+        stage[0], stage[1], stage[2] = n, splits, chunk
+        stage[4: 4 + 2 * n] = work.reshape(-1)
+        self.cuda_graph_plan_buf[: 4 + 2 * n].copy_(stage[: 4 + 2 * n], non_blocking=True)
+        if stage.is_pinned():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._plan_stage_ev[i] = ev
+
+    def _graph_metadata(self, bs: int, kv_indptr) -> ForwardMetadata:
+        cap = bs * self.max_kv_splits
+        plan = self.cuda_graph_plan_buf[:4]
+        work = self.cuda_graph_plan_buf[4: 4 + 2 * cap].view(cap, 2)
+        return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, self.max_kv_splits,
+                               self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
                                                  forward_mode, spec_info):
@@ -182,19 +228,24 @@ class MiAttnBackend(AttentionBackend):
             raise ValueError(f"Invalid forward mode: {forward_mode=} for graph capture.")
         kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
-        # the split count is baked into the captured launch: size it for a long-context batch
-        splits = self._choose_splits(bs, bs * min(self.max_context_len, 2048))
-        self.cuda_graph_splits[bs] = splits
-        self.forward_metadata = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, splits,
-                                                self.cuda_graph_workspace)
+        # the captured launch covers the whole capacity bs x max_kv_splits of the work list; which entries are live,
+        # the split count and the split size come from the device-side plan.  A valid plan must be in place for the
+        # capture-time warm-up runs too (the capture inputs are fill values: one split per request)
+        if self.max_kv_splits > 1:
+            self._write_graph_plan(bs, bs * self.get_cuda_graph_seq_len_fill_value(), None)
+            self.forward_metadata = self._graph_metadata(bs, kv_indptr)
+        else:
+            self.forward_metadata = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, 1, None)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
         if not forward_mode.is_decode_or_idle() or spec_info is not None:
             raise ValueError(f"Invalid forward mode: {forward_mode=} for graph replay.")
-        # no allocation, no host sync: two kernels into persistent buffers (triton_backend.py:544-566)
+        # no allocation, no host sync: two kernels into persistent buffers (triton_backend.py:544-566) and the plan
         kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
+        if self.max_kv_splits > 1:
+            self._write_graph_plan(bs, int(seq_lens_sum), seq_lens_cpu)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # triton_backend.py:629 -- padded rows attend one key (slot 0 sink via req_to_token)

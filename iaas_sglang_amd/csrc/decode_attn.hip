@@ -29,6 +29,9 @@ struct DecodeParams {
   float* ws_o;   // [B][Hq][splits][D]
   float* ws_ml;  // [B][Hq][splits][2]
   int32_t num_q_heads, num_kv_heads, group, num_splits;
+  const int32_t* plan;   // optional DEVICE-side plan {num_work, num_splits, split_chunk}: overrides the three scalars
+                         // below, so a captured launch (grid = capacity of the work list) follows a plan the host
+                         // rewrites before every replay; workgroups beyond num_work exit
   const int32_t* work;   // optional work list [num_work][2] = (request, split): launch order and non-empty splits only
   int32_t num_work;
   int32_t split_chunk;   // > 0: every split covers this many keys (multiple of 16) unless the request needs more
@@ -117,20 +120,23 @@ void decode_attn_kernel(const DecodeParams p) {
   // (with the split index fastest, fixed-size splits s = 0..k of every request landed on XCDs 0..k only)
   // work list (ragged batches): the host hands out only non-empty (request, split) pairs, full chunks first and the
   // short remainders last, so the tail of the launch is filled with small pieces (longest-first packing)
+  if (p.plan && (int)blockIdx.x >= p.plan[0]) return;
   const int b = p.work ? p.work[2 * blockIdx.x] : (int)blockIdx.x;
   const int hk = blockIdx.y * W + wave;
   const int s = p.work ? p.work[2 * blockIdx.x + 1] : (int)blockIdx.z;
   if (hk >= p.num_kv_heads) return;
   const int group = p.group;
-  const int nsplit = p.num_splits;
+  const int nsplit = p.num_splits;                       // workspace stride (the capacity when a plan is given)
+  const int nsplit_eff = p.plan ? p.plan[1] : nsplit;    // splits of this launch
+  const int32_t chunk_eff = p.plan ? p.plan[2] : p.split_chunk;
 
   const int32_t base = p.kv_indptr[b];
   const int32_t S = p.kv_indptr[b + 1] - base;
-  int32_t per = (S + nsplit - 1) / nsplit;
+  int32_t per = (S + nsplit_eff - 1) / nsplit_eff;
   per = (per + 15) & ~15;
   // fixed-size splits balance RAGGED batches (every non-empty workgroup walks <= split_chunk keys, short requests
   // leave their trailing splits empty); a request longer than nsplit * split_chunk falls back to S / nsplit
-  per = max(per, p.split_chunk);
+  per = max(per, chunk_eff);
   const int32_t start = s * per;
   const int32_t end = min(S, start + per);
   const int hq0 = hk * group;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
                                                            int32_t nsplit, int64_t stride_o_tok,
                                                            uint8_t* __restrict__ o_q, const float* __restrict__ o_qscale,
                                                            float out_scale, const int32_t* __restrict__ kv_indptr,
-                                                           int32_t split_chunk) {
+                                                           int32_t split_chunk, const int32_t* __restrict__ plan) {
   constexpr int EPL = D / 64 > 0 ? D / 64 : 1;  // elements per lane
   const int lane = threadIdx.x & 63;
   const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -384,9 +390,10 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   {
     const int64_t bq = bh / num_q_heads;
     const int32_t S = kv_indptr[bq + 1] - kv_indptr[bq];
-    int32_t per = (S + nsplit - 1) / nsplit;
-    per = max((per + 15) & ~15, split_chunk);
-    nvalid = per > 0 ? min(nsplit, (S + per - 1) / per) : 0;
+    const int ne = plan ? plan[1] : nsplit;
+    int32_t per = (S + ne - 1) / ne;
+    per = max((per + 15) & ~15, plan ? plan[2] : split_chunk);
+    nvalid = per > 0 ? min(ne, (S + per - 1) / per) : 0;
   }
   float M = -INFINITY;
   for (int s = 0; s < nvalid; ++s) M = fmaxf(M, ml[2 * s]);
@@ -476,7 +483,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
                             int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                             int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
                             float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work,
-                            int dtype, void* stream, void* o_fp8, const float* o_scale, bool kv8 = false,
+                            const int32_t* plan, int dtype, void* stream, void* o_fp8, const float* o_scale, bool kv8 = false,
                             float k_scale = 1.f, float v_scale = 1.f) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
@@ -506,8 +513,9 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   p.num_q_heads = (int32_t)num_q_heads; p.num_kv_heads = (int32_t)num_kv_heads;
   p.group = (int32_t)(num_q_heads / num_kv_heads); p.num_splits = (int32_t)num_splits;
   p.split_chunk = (int32_t)split_chunk;
-  MI_CHECK_ARG(!work || (num_work > 0 && num_work <= 0x7fffffff && num_splits > 1 && split_chunk > 0));
-  p.work = work; p.num_work = (int32_t)num_work;
+  MI_CHECK_ARG(!work || (num_work > 0 && num_work <= 0x7fffffff && num_splits > 1 && (split_chunk > 0 || plan)));
+  MI_CHECK_ARG(!plan || (work && num_splits > 1));
+  p.work = work; p.num_work = (int32_t)num_work; p.plan = plan;
   p.stride_q_tok = stride_q_tok; p.stride_o_tok = stride_o_tok;
   p.stride_k_slot = stride_k_slot; p.stride_v_slot = stride_v_slot;
   // fp8 KV: logits = sm_scale * k_scale * (q . k8), out = v_scale * softmax . v8
@@ -532,14 +540,14 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
     const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
     if (dtype == MI_BF16) {
       if (head_dim == 128)
-        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
+        decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk, p.plan);
       else
-        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
+        decode_merge_kernel<bf16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk, p.plan);
     } else {
       if (head_dim == 128)
-        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
+        decode_merge_kernel<f16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk, p.plan);
       else
-        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk);
+        decode_merge_kernel<f16_t, 64><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (f16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk, p.plan);
     }
     MI_CHECK_LAUNCH();
   }
@@ -551,10 +559,10 @@ extern "C" int mi_decode_attn(const void* q, const void* k_buf, const void* v_bu
                               int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                               int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                               int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                              float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream) {
+                              float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype, void* stream) {
   MI_CHECK_ARG(o != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, plan, dtype,
                           stream, nullptr, nullptr);
 }
 
@@ -563,11 +571,11 @@ extern "C" int mi_decode_attn_fp8out(const void* q, const void* k_buf, const voi
                                      const int32_t* kv_indices, void* workspace, int64_t batch, int64_t num_q_heads,
                                      int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
                                      int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
-                                     int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype,
-                                     void* stream) {
+                                     int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan,
+                                     int dtype, void* stream) {
   MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr);
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, plan, dtype,
                           stream, o_fp8, o_scale);
 }
 
@@ -576,8 +584,8 @@ extern "C" int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void
                                     const int32_t* kv_indptr, const int32_t* kv_indices, void* workspace, int64_t batch,
                                     int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                                     int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
-                                    float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream) {
+                                    float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype, void* stream) {
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
-                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, dtype,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, plan, dtype,
                           stream, o_fp8, o_scale, true, k_scale, v_scale);
 }

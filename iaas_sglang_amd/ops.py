@@ -128,12 +128,17 @@ def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_sp
     return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4
 
 
-def _work_args(work: Optional[torch.Tensor]):
-    """(pointer, count) of an optional decode work list: int32 [n, 2] = (request, split), contiguous, on the device."""
+def _work_args(work, plan: Optional[torch.Tensor] = None):
+    """(pointer, count, plan pointer) of an optional decode work list: int32 [n, 2] = (request, split), contiguous, on
+    the device; `work` may be a (list, plan) pair: plan = device int32 {num_work, num_splits, split_chunk}."""
+    if isinstance(work, tuple):
+        work, plan = work
     if work is None:
-        return None, 0
+        return None, 0, None
     assert work.dtype == torch.int32 and work.dim() == 2 and work.shape[1] == 2 and work.is_contiguous() and work.is_cuda
-    return _ptr(work), work.shape[0]
+    if plan is not None:
+        assert plan.dtype == torch.int32 and plan.numel() >= 3 and plan.is_cuda and plan.is_contiguous()
+    return _ptr(work), work.shape[0], _ptr(plan)
 
 
 def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, o: torch.Tensor,

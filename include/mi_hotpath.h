@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
@@ -105,6 +105,10 @@ int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_heads, int64
  *   work (nullable, needs split_chunk > 0): int32 [num_work][2] = (request, split) pairs to launch, in launch order --
  *   only the non-empty splits of a ragged batch, full chunks first and short remainders last (longest-first
  *   packing of the last round of workgroups); splits not listed must be empty.
+ *   plan (nullable, needs work): DEVICE int32 {num_work, num_splits, split_chunk} read by the kernels instead of the
+ *   scalar arguments; the launch then covers the whole capacity `num_work` of the list (extra workgroups exit) and
+ *   `num_splits` is the workspace stride, so a hipGraph-captured launch follows a plan the host rewrites before each
+ *   replay (init_forward_metadata_replay_cuda_graph hands the host-side lengths over, triton_backend.py:544-566).
  * replaces: decode_attention_fwd (stage1 + stage2), triton_ops/decode_attention.py:677-728;
  * oracle: TorchNativeAttnBackend._run_sdpa_forward_decode, torch_native_backend.py:112-180. */
 int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
@@ -112,7 +116,8 @@ int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
                    int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
                    int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_k_slot,
                    int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
-                   int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream);
+                   int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype,
+                   void* stream);
 
 /* mi_decode_attn with the static per-tensor FP8 quantisation of the FOLLOWING linear (o_proj) fused into the
  * output stage: o_fp8 [B, Hq*D] contiguous = quant(o rounded to `dtype`, *o_scale), bit-identical to
@@ -124,7 +129,7 @@ int mi_decode_attn_fp8out(const void* q, const void* k_buf, const void* v_buf, v
                           int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                           int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot,
                           float sm_scale, float logit_cap, int64_t num_splits, int64_t split_chunk,
-                          const int32_t* work, int64_t num_work, int dtype, void* stream);
+                          const int32_t* work, int64_t num_work, const int32_t* plan, int dtype, void* stream);
 
 /* mi_decode_attn over an fp8 (e4m3fn) KV pool: k_buf/v_buf hold bytes, stride_*_slot are in BYTES, head_dim 128.
  *   o[b,h] = v_scale * softmax_j(sm_scale * k_scale * q[b,h] . k8[...]) . v8[...]   (K is converted up to the q
@@ -137,7 +142,8 @@ int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void* v_buf, vo
                          int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
                          int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_k_slot,
                          int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
-                         int64_t split_chunk, const int32_t* work, int64_t num_work, int dtype, void* stream);
+                         int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype,
+                         void* stream);
 
 /* Ragged extend (prefill-with-prefix) attention.
  *   q_ext [E,Hq,D], k_ext/v_ext [E,Hkv,D] : the new tokens, request i owns rows

@@ -108,14 +108,21 @@ def test_tiny_llama_fp8_extend_then_decode(weight_range, tol, scheme):
         assert float((logits.float().cpu() - ref).abs().max()) < tol
 
 
-def test_backend_graph_capture_replay_matches_eager():
+@pytest.mark.parametrize("ctx,trials", [
+    (512, [[300, 17, 450, 1], [5, 5, 5, 5], [511, 300, 2, 64]]),
+    # long enough for the ragged plan (fixed chunks + launch list) and for several uniform split counts: the captured
+    # launch must follow whatever plan replay writes
+    (4096, [[3000, 40, 700, 513], [2048, 2048, 2048, 2048], [1, 1, 1, 1], [4000, 3999, 16, 2100], [600, 600, 600, 600]]),
+])
+def test_backend_graph_capture_replay_matches_eager(ctx, trials):
     """Decode under hipGraph: capture with one batch, replay with other seq_lens / slots
     (cuda_graph_runner.py:456-696 protocol: persistent inputs, metadata replay, padded rows)."""
     from iaas_sglang_amd import harness as H
     from iaas_sglang_amd.attention_backend import MiAttnBackend
 
     shape, dtype = H.TINY, torch.bfloat16
-    runner = H.make_runner(shape, max_reqs=8, ctx=512, pool_tokens=3000, dtype=dtype, device=DEV, fill_kv=True)
+    runner = H.make_runner(shape, max_reqs=8, ctx=ctx, pool_tokens=max(3000, 4 * ctx), dtype=dtype, device=DEV,
+                           fill_kv=True)
     backend = MiAttnBackend(runner)
     bs = 4
     backend.init_cuda_graph_state(bs, bs)
@@ -135,7 +142,7 @@ def test_backend_graph_capture_replay_matches_eager():
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = backend.forward(q, k, v, layer, fb)
-    for trial, lens in enumerate([[300, 17, 450, 1], [5, 5, 5, 5], [511, 300, 2, 64]]):
+    for trial, lens in enumerate(trials):
         fb2 = H.make_decode_batch(runner, MiAttnBackend(runner), bs, 0, DEV, seed=10 + trial,
                                   ragged=torch.tensor(lens))
         rpi.copy_(fb2.req_pool_indices); seq_lens.copy_(fb2.seq_lens); out_loc.copy_(fb2.out_cache_loc)

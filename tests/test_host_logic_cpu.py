@@ -94,7 +94,21 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     assert all(s < int(lens[b]) // 512 for b, s in got[:nfull])
     tail = [int(lens[b]) % 512 for b, s in got[nfull:]]
     assert tail == sorted(tail, reverse=True) and all(t > 0 for t in tail)
-    assert be._choose_split_plan(128, 128 * 2048, None) == (2, 0, None)   # no host-side lengths (graph replay)
+    assert be._choose_split_plan(128, 128 * 2048, None) == (2, 0, None)   # no host-side lengths
+    # graph replay: the plan always carries a list (the captured launch reads it); uniform = the full grid, split outermost
+    ns, chunk, wl = be._plan_on_host(4, 4 * 2048, torch.full((4,), 2048), force_list=True)
+    assert chunk == 0 and wl.tolist() == [[b, s_] for s_ in range(ns) for b in range(4)]
+    # ... and lands, with its header, in the persistent device buffer (a CPU tensor here)
+    be.device = "cpu"
+    be.max_context_len = 64
+    monkeypatch.setattr(ab.ops, "decode_workspace_numel", lambda *a: 16)
+    be.init_cuda_graph_state(128, 128, kv_indices_buf=torch.zeros(8, dtype=torch.int32))
+    be._write_graph_plan(128, int(lens.sum()), lens)
+    buf = be.cuda_graph_plan_buf
+    assert buf[:3].tolist() == [work.shape[0], -(-int(lens.max()) // 512), 512]
+    assert torch.equal(buf[4: 4 + 2 * work.shape[0]].view(-1, 2), work)
+    md = be._graph_metadata(128, None)
+    assert md.num_kv_splits == be.max_kv_splits and md.work[0].shape == (128 * be.max_kv_splits, 2) and md.work[1].numel() == 4
     fb = types.SimpleNamespace(batch_size=1, forward_mode=_compat.ForwardMode.DRAFT_EXTEND, spec_info=None)
     with pytest.raises(NotImplementedError):
         be.init_forward_metadata(fb)                          # draft-side speculative modes: out of scope, loud

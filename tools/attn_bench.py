@@ -44,6 +44,16 @@ if os.environ.get('WORKLIST', '0') == '1':      # the backend's ragged plan: fix
     ns_, CHUNK, WORK = be._choose_split_plan(B, tot, sl.cpu())
     os.environ['SPLITS'] = str(ns_)
     print(f'work list: {0 if WORK is None else WORK.shape[0]} entries, chunk {CHUNK}, splits {ns_}', flush=True)
+    if os.environ.get('PLAN', '0') == '1':      # the graph-replay form: capacity-sized launch, plan read on the device
+        ns_, CHUNK, wl = be._plan_on_host(B, tot, sl.cpu(), force_list=True)
+        cap = B * be.max_kv_splits
+        buf = torch.zeros(4 + 2 * cap, dtype=torch.int32)
+        buf[0], buf[1], buf[2] = wl.shape[0], ns_, CHUNK
+        buf[4: 4 + 2 * wl.shape[0]] = wl.reshape(-1)
+        buf = buf.to(dev)
+        WORK, CHUNK = (buf[4:].view(cap, 2), buf[:4]), 0
+        os.environ['SPLITS'] = str(be.max_kv_splits)
+        print(f'device plan: {wl.shape[0]} live of {cap} entries, splits {ns_}', flush=True)
 for ns in [int(x) for x in os.environ.get("SPLITS", "1,2,4,8").split(",")]:
     ws = torch.empty(max(1, ops.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=dev)
     for k, v in pools:
