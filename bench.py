@@ -95,6 +95,25 @@ def make_custom_ar(world, rank, dev, msg_bytes):
     y = ca.all_reduce(x)
     torch.cuda.synchronize()
     ok = bool(torch.equal(y, ref)) and not ca.timed_out()
+    if ok:      # the fused all-reduce + add + RMSNorm + fp8 form must give the bits of the unfused sequence
+        from iaas_sglang_amd import ops
+        rows, Hh = max(1, msg_bytes // 2 // 4096), 4096
+        gc = torch.Generator(device=dev).manual_seed(7)
+        xs = torch.randn(rows, Hh, device=dev, generator=torch.Generator(device=dev).manual_seed(200 + rank)).to(torch.bfloat16)
+        res = torch.randn(rows, Hh, device=dev, generator=gc).to(torch.bfloat16)
+        w = torch.randn(Hh, device=dev, generator=gc).to(torch.bfloat16)
+        qs = torch.tensor([0.02], device=dev)
+        r1, r2 = res.clone(), res.clone()
+        want = ops.rmsnorm_fp8(ca.all_reduce(xs), w, 1e-5, qs, residual=r1)
+        _, got = ca.all_reduce_add_rmsnorm(xs, r2, w, 1e-5, q_scale=qs, want_out=False)
+        torch.cuda.synchronize()
+        fused_ok = torch.tensor([int(torch.equal(got.view(torch.uint8), want.view(torch.uint8)) and torch.equal(r1, r2)
+                                     and not ca.timed_out())], device=dev)
+        torch.distributed.all_reduce(fused_ok, op=torch.distributed.ReduceOp.MIN)
+        if int(fused_ok.item()) != 1:
+            ca.fuse_norm = False
+            if rank == 0:
+                print("[bench] fused all-reduce+norm self-check failed; using the unfused sequence", file=sys.stderr)
     flag = torch.tensor([1 if ok else 0], device=dev)
     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
     if int(flag.item()) != 1:

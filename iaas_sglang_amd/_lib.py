@@ -59,6 +59,8 @@ SIGNATURES = {
     "mi_ar_destroy": (_int, [_p]),
     "mi_ar_error": (_int, [_p]),
     "mi_ar_all_reduce": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "mi_ar_staging": (_p, [_p]),
+    "mi_ar_all_reduce_add_rmsnorm": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _int, _p]),
     "mi_rmsnorm": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
     "mi_rmsnorm_fp8": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p]),
     "mi_silu_and_mul_fp8": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),

@@ -151,6 +151,112 @@ __global__ __launch_bounds__(AR_THREADS) void ar_2stage_kernel(const ArPeers pr,
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
+// ------------------------------------------------- all-reduce fused with (add +) RMSNorm (+ static fp8 quant)
+// The consumer of every TP all-reduce in a Llama layer is `x32 = h + residual; residual <- x32; out = norm(x32) * w`
+// (layers/layernorm.py:128-146; the reference fuses it on the flashinfer path, layers/flashinfer_comm_fusion.py and
+// layers/communicator.py).  Here the LAST phase of the all-reduce -- the pass in which a rank reads the reduced
+// values anyway -- is that row-wise consumer: 2-stage: reduce-scatter as above, then the gather phase reads each
+// row's packs from their owners' tmp straight into registers, adds the residual, norms, and writes
+// residual / out / fp8(out); the reduced tensor itself never goes to memory.  1-stage: the same with the packs
+// reduced on the fly.  Each 256-thread half of the workgroup owns one row with exactly the vector->thread mapping
+// and reduction order of rmsnorm_kernel (elementwise.hip), and the reduced sum is rounded to T first, so the
+// results are bit-identical to mi_ar_all_reduce followed by mi_rmsnorm[_fp8].
+template <typename T> __device__ __forceinline__ void ar_unpack8(const uint4& u, float (&f)[8]) { ArPack16<T>::up(u, f); }
+
+__device__ __forceinline__ uint2 ar_quant8_static(const float (&f)[8], float inv) {
+  uint32_t lo = 0, hi = 0;
+  auto c = [](float v) { return fmaxf(fminf(v, 448.0f), -448.0f); };
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[0] * inv), c(f[1] * inv), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[2] * inv), c(f[3] * inv), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[4] * inv), c(f[5] * inv), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c(f[6] * inv), c(f[7] * inv), hi, true);
+  return make_uint2(lo, hi);
+}
+
+template <typename T, int VPT, bool TWO_STAGE>
+__global__ __launch_bounds__(AR_THREADS) void ar_add_rmsnorm_kernel(const ArPeers pr, int rank, int world, int64_t rows,
+                                                                    int64_t H, T* __restrict__ residual, int64_t ldr,
+                                                                    const T* __restrict__ w, float eps,
+                                                                    T* __restrict__ out, int64_t ldo,
+                                                                    uint8_t* __restrict__ q_out,
+                                                                    const float* __restrict__ q_scale) {
+  static_assert(AR_THREADS == 512, "two 256-thread row groups per workgroup");
+  __shared__ float red[2][4];
+  ArSignal* self = pr.sig[rank];
+  const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const int64_t nvec = H / 8, packs = rows * nvec;
+  const int64_t part = packs / world;
+  ar_barrier<false>(pr, rank, world, false, flag);
+  if (TWO_STAGE) {
+    const int64_t lo = rank * part, hi = (rank == world - 1) ? packs : lo + part;
+    uint4* mytmp = (uint4*)pr.tmp[rank];
+    for (int64_t i = lo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < hi; i += (int64_t)gridDim.x * AR_THREADS)
+      mytmp[i - lo] = ar_reduce_pack<T>(pr, world, i);
+    ar_barrier<true>(pr, rank, world, true, flag);
+  }
+  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+  for (int64_t row0 = (int64_t)blockIdx.x * 2; row0 < rows; row0 += (int64_t)gridDim.x * 2) {
+    const int64_t row = row0 + half;
+    const bool valid = row < rows;
+    float v[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int64_t c = t + i * 256;
+      if (valid && c < nvec) {
+        const int64_t idx = row * nvec + c;
+        uint4 u;
+        if (TWO_STAGE) {
+          const int64_t o = idx / part;
+          const int owner = o < world ? (int)o : world - 1;
+          u = ((const uint4*)pr.tmp[owner])[idx - owner * part];
+        } else {
+          u = ar_reduce_pack<T>(pr, world, idx);
+        }
+        ar_unpack8<T>(u, v[i]);
+        if (residual) {
+          float r[8];
+          ar_unpack8<T>(*(const uint4*)(residual + row * ldr + c * 8), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] += r[j];
+          *(uint4*)(residual + row * ldr + c * 8) = ArPack16<T>::down(v[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[half][(threadIdx.x >> 6) & 3] = ss;
+    __syncthreads();
+    ss = red[half][0] + red[half][1] + red[half][2] + red[half][3];
+    const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int64_t c = t + i * 256;
+      if (valid && c < nvec) {
+        float wf[8], o[8];
+        ar_unpack8<T>(*(const uint4*)(w + c * 8), wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
+        if (out) *(uint4*)(out + row * ldo + c * 8) = ArPack16<T>::down(o);
+        if (q_out) {
+          const float qs = *q_scale;
+          const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = round_to<T>(o[j]);
+          *(uint2*)(q_out + row * H + c * 8) = ar_quant8_static(o, qinv);
+        }
+      }
+    }
+    __syncthreads();  // red[] is reused by the next pair of rows
+  }
+  // 1-stage: nobody overwrites staging before all have read it.  2-stage: as in ar_2stage_kernel, a peer can write
+  // its tmp again only after the next call's start barrier, which every rank reaches after the reads above
+  if (!TWO_STAGE) ar_barrier<false>(pr, rank, world, true, flag);
+  if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
+}
+
 // --------------------------------------------------------------------------- host side
 extern "C" int64_t mi_ar_shared_bytes(int64_t max_bytes) {
   return (int64_t)sizeof(ArSignal) + 2 * ((max_bytes + 255) & ~(int64_t)255);
@@ -227,8 +333,10 @@ extern "C" int mi_ar_all_reduce(void* ctx, const void* inp, void* out, int64_t b
             (long long)c->max_bytes);
   MI_CHECK_ARG((((uintptr_t)inp | (uintptr_t)out) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
-  // eager path: stage the input in the IPC-mapped buffer (custom_all_reduce.py:446-450)
-  if (hipMemcpyAsync((void*)c->peers.stage[c->rank], inp, (size_t)bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+  // eager path: stage the input in the IPC-mapped buffer (custom_all_reduce.py:446-450) -- unless the producer
+  // already wrote it there (mi_ar_staging: the role of the reference's registered / graph buffers)
+  if (inp != (const void*)c->peers.stage[c->rank] &&
+      hipMemcpyAsync((void*)c->peers.stage[c->rank], inp, (size_t)bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
     MI_FAIL(MI_ERR_LAUNCH, "mi_ar_all_reduce: staging copy failed");
   const int64_t packs = bytes / 16;
   // policy of custom_all_reduce_hip.cuh:541-551: world 2 -> 1-stage; else 1-stage below 256 KiB (512 KiB for <= 4)
@@ -249,6 +357,56 @@ extern "C" int mi_ar_all_reduce(void* ctx, const void* inp, void* out, int64_t b
     else AR_LAUNCH(ar_2stage_kernel, float);
   }
 #undef AR_LAUNCH
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// The rank's own IPC-mapped staging buffer (max_bytes): a producer (the row-parallel GEMM) that writes its output
+// here and passes this pointer as `inp` skips the staging copy -- what register_buffer / register_graph_buffers
+// (sgl_kernel_ops.h:58-68, custom_all_reduce.py:387-412) achieve in the reference by registering the producer's
+// own buffers after capture; here one persistent buffer is registered once, so there is nothing to re-register.
+extern "C" void* mi_ar_staging(void* ctx) {
+  ArCtx* c = (ArCtx*)ctx;
+  return c ? (void*)c->peers.stage[c->rank] : nullptr;
+}
+
+extern "C" int mi_ar_all_reduce_add_rmsnorm(void* ctx, const void* inp, void* residual, const void* weight, void* out,
+                                            void* q_out, const float* q_scale, int64_t rows, int64_t H, int64_t ldr,
+                                            int64_t ldo, float eps, int dtype, void* stream) {
+  ArCtx* c = (ArCtx*)ctx;
+  MI_CHECK_ARG(c && inp && weight && (out || q_out) && rows >= 0 && H > 0);
+  MI_CHECK_ARG(!q_out || q_scale);
+  if (rows == 0) return MI_OK;
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
+  const int64_t bytes = rows * H * 2;
+  if (H % 8 != 0 || H > 256 * 8 * 8 || ldo % 8 || (residual && ldr % 8) || bytes > c->max_bytes)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_ar_all_reduce_add_rmsnorm: H %% 8 == 0, H <= 16384, rows*H*2 <= %lld (rows=%lld H=%lld)",
+            (long long)c->max_bytes, (long long)rows, (long long)H);
+  MI_CHECK_ARG((((uintptr_t)inp | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)out) & 15) == 0);
+  MI_CHECK_ARG(((uintptr_t)q_out & 7) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (inp != (const void*)c->peers.stage[c->rank] &&
+      hipMemcpyAsync((void*)c->peers.stage[c->rank], inp, (size_t)bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    MI_FAIL(MI_ERR_LAUNCH, "mi_ar_all_reduce_add_rmsnorm: staging copy failed");
+  const int64_t packs = bytes / 16;
+  const bool one_stage = c->world == 2 || (c->world <= 4 && bytes < 512 * 1024) || bytes < 256 * 1024 ||
+                         packs < c->world;
+  int blocks = (int)cdiv64(rows, 2);
+  if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
+  const int vpt = (int)cdiv64(H / 8, 256);
+#define ARN_LAUNCH(TT, V, TS)                                                                                         \
+  ar_add_rmsnorm_kernel<TT, V, TS><<<blocks, AR_THREADS, 0, st>>>(c->peers, c->rank, c->world, rows, H, (TT*)residual, \
+                                                                  ldr, (const TT*)weight, eps, (TT*)out, ldo,          \
+                                                                  (uint8_t*)q_out, q_scale)
+#define ARN_VPT(TT, TS)                                                                             \
+  do {                                                                                              \
+    if (vpt <= 1) ARN_LAUNCH(TT, 1, TS); else if (vpt <= 2) ARN_LAUNCH(TT, 2, TS);                   \
+    else if (vpt <= 4) ARN_LAUNCH(TT, 4, TS); else ARN_LAUNCH(TT, 8, TS);                            \
+  } while (0)
+  if (dtype == MI_BF16) { if (one_stage) ARN_VPT(bf16_t, false); else ARN_VPT(bf16_t, true); }
+  else { if (one_stage) ARN_VPT(f16_t, false); else ARN_VPT(f16_t, true); }
+#undef ARN_VPT
+#undef ARN_LAUNCH
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -8,6 +8,7 @@ exchanged through a CPU (gloo) process group with all_gather_object, exactly lik
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -31,6 +32,7 @@ class CustomAllreduce:
         self._ctx = None
         self._own = C.c_void_p()
         self._peers: List[Optional[int]] = []
+        self._stage_bytes = None
         self.init_error = ""
         if self.world_size == 1 or self.world_size not in self._SUPPORTED_WORLD_SIZES:
             return
@@ -76,6 +78,7 @@ class CustomAllreduce:
         self.disabled = False
 
     def _release(self):
+        self._stage_bytes = None
         if self._ctx:
             lib.mi_ar_destroy(self._ctx)
             self._ctx = None
@@ -100,6 +103,51 @@ class CustomAllreduce:
         check(lib.mi_ar_all_reduce(self._ctx, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
                                    _DT[inp.dtype], torch.cuda.current_stream().cuda_stream), "mi_ar_all_reduce")
         return out
+
+    def staging(self, shape, dtype: torch.dtype) -> torch.Tensor:
+        """A tensor over the rank's own IPC-mapped staging buffer: a producer (the row-parallel GEMM) that writes its
+        output here saves the staging copy of the next all_reduce / all_reduce_add_rmsnorm on it -- the job of the
+        reference's register_buffer / register_graph_buffers (custom_all_reduce.py:387-412), without re-registration:
+        the buffer is persistent, so captured graphs can use it as it is."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        if self.disabled or nbytes > self.max_size:
+            raise MiHotpathError(f"CustomAllreduce.staging: {nbytes} bytes do not fit the registered {self.max_size}")
+        if self._stage_bytes is None:
+            class _Dev:          # the CUDA array interface is how torch wraps foreign device memory without a copy
+                __cuda_array_interface__ = {"shape": (self.max_size,), "typestr": "|u1", "version": 2,
+                                            "data": (int(lib.mi_ar_staging(self._ctx)), False)}
+            self._stage_owner = _Dev()
+            self._stage_bytes = torch.as_tensor(self._stage_owner, device=self.device)
+            assert self._stage_bytes.data_ptr() == int(lib.mi_ar_staging(self._ctx))
+        return self._stage_bytes[:nbytes].view(dtype).view(*shape)
+
+    def all_reduce_add_rmsnorm(self, inp: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                               eps: float, q_scale: Optional[torch.Tensor] = None, want_out: bool = True):
+        """sum over ranks of inp [rows, H], then `x = sum + residual; residual <- x; out = rmsnorm(x) * weight` in the
+        same kernel (see mi_ar_all_reduce_add_rmsnorm).  Returns (out or None, fp8(out) or None): bit-identical to
+        all_reduce followed by ops.rmsnorm / ops.rmsnorm_fp8."""
+        assert inp.dim() == 2 and inp.is_contiguous() and inp.dtype in (torch.bfloat16, torch.float16)
+        rows, H = inp.shape
+        assert residual is None or (residual.shape == inp.shape and residual.stride(1) == 1 and residual.dtype == inp.dtype)
+        assert weight.dtype == inp.dtype and weight.is_contiguous() and weight.numel() == H
+        out = torch.empty_like(inp) if (want_out or q_scale is None) else None
+        q = torch.empty((rows, H), dtype=torch.float8_e4m3fn, device=inp.device) if q_scale is not None else None
+        check(lib.mi_ar_all_reduce_add_rmsnorm(
+            self._ctx, inp.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
+            out.data_ptr() if out is not None else None, q.data_ptr() if q is not None else None,
+            q_scale.data_ptr() if q_scale is not None else None, rows, H,
+            residual.stride(0) if residual is not None else H, H, float(eps), _DT[inp.dtype],
+            torch.cuda.current_stream().cuda_stream), "mi_ar_all_reduce_add_rmsnorm")
+        return out, q
+
+    fuse_norm = os.environ.get("MI_AR_FUSE_NORM", "1") != "0"   # switch for A/B runs and for a failed self-check
+
+    def should_fuse_norm(self, rows: int, H: int, dtype: torch.dtype) -> bool:
+        return (self.fuse_norm and not self.disabled and dtype in (torch.bfloat16, torch.float16) and H % 8 == 0 and H <= 16384
+                and rows * H * 2 <= self.max_size)
 
     def custom_all_reduce(self, inp: torch.Tensor) -> Optional[torch.Tensor]:
         """None means: fall through to RCCL (parallel_state.py:495-500)."""

@@ -97,8 +97,10 @@ class Linear(torch.nn.Module):
         f = getattr(self.quant_method, "static_input_scale", None)
         return f(self) if f is not None else None
 
-    def forward_prequantized(self, qx, out_dtype):
-        return self.quant_method.apply_prequantized(self, qx, out_dtype, self.bias)
+    def forward_prequantized(self, qx, out_dtype, out=None):
+        if out is None:
+            return self.quant_method.apply_prequantized(self, qx, out_dtype, self.bias)
+        return self.quant_method.apply_prequantized(self, qx, out_dtype, self.bias, out)
 
     fuse_producer_quant = True   # norm/activation kernels emit fp8 for static-scale linears
 
@@ -212,6 +214,26 @@ class LlamaStack:
     def _all_reduce(self, x):
         return tensor_model_parallel_all_reduce(x, self.tp, self.group, self.custom_ar)   # linear.py:1376-1378
 
+    def _row_parallel_add_norm(self, lin, qx, residual, norm_w, q_scale, want_out=False):
+        """Row-parallel linear -> all-reduce -> add + RMSNorm (+ fp8 quant for the next linear), TP > 1
+        (linear.py:1360-1382 then layernorm.py:128-146).  With the native all-reduce: the GEMM writes straight into
+        the registered staging buffer and ONE kernel reduces over the ranks, adds the residual, norms and quantises
+        (3 launches: GEMM partials, slab reduce, fused all-reduce); otherwise GEMM, RCCL/gloo all-reduce, norm kernel.
+        Returns (out or None, fp8 or None); residual is updated in place.  Same bits either way."""
+        M, H = qx.shape[0], self.shape.hidden
+        ca = self.custom_ar
+        if ca is not None and ca.should_fuse_norm(M, H, self.dtype):
+            h = lin.forward_prequantized(qx, self.dtype, out=ca.staging((M, H), self.dtype))
+            return ca.all_reduce_add_rmsnorm(h, residual, norm_w, self.shape.rms_eps, q_scale=q_scale,
+                                             want_out=want_out or q_scale is None)
+        h = self._all_reduce(lin.forward_prequantized(qx, self.dtype))
+        out = q = None
+        if q_scale is not None:
+            q = ops.rmsnorm_fp8(h, norm_w, self.shape.rms_eps, q_scale, residual=residual)
+        else:
+            out = ops.rmsnorm(h, norm_w, self.shape.rms_eps, residual=residual)
+        return out, q
+
     def calibrate_static_input_scales(self, hidden, positions, fb, backend):
         """Give every static-activation linear a realistic `input_scale` (amax/448 of one forward pass),
         standing in for the calibrated scales a serialized FP8 checkpoint carries."""
@@ -240,7 +262,8 @@ class LlamaStack:
         """The same layer sequence as forward() with each FP8 linear fused with its consumer:
         norm+quant | qkv+rope+kv-write | attention(+quant) | o+add+norm+quant | gate_up+silu*mul+quant |
         down+add+norm(next layer)+quant  -- 7 launches per layer instead of 15, bit-identical results.
-        With TP>1 the row-parallel o/down outputs need the all-reduce first, so those two stay unfused."""
+        With TP>1 the row-parallel o/down outputs need the all-reduce first: there the add + norm + quant is fused
+        into the all-reduce kernel instead (_row_parallel_add_norm)."""
         s, D = self.shape, self.shape.head_dim
         pool = fb.token_to_kv_pool
         residual = hidden
@@ -264,8 +287,7 @@ class LlamaStack:
                 _, qx = L.o.quant_method.apply_add_rmsnorm(L.o, a8, residual, L.post_norm, s.rms_eps,
                                                            L.gate_up.input_scale)
             else:
-                h = self._all_reduce(L.o.forward_prequantized(a8, self.dtype))
-                qx = ops.rmsnorm_fp8(h, L.post_norm, s.rms_eps, L.gate_up.input_scale, residual=residual)
+                _, qx = self._row_parallel_add_norm(L.o, a8, residual, L.post_norm, L.gate_up.input_scale)
             act8 = L.gate_up.quant_method.apply_silu_mul(L.gate_up, qx, L.down.input_scale, self.dtype)
             last = i + 1 == len(self.layers)
             nw = self.final_norm if last else self.layers[i + 1].input_norm
@@ -273,11 +295,7 @@ class LlamaStack:
             if self.tp == 1:
                 x, qx = L.down.quant_method.apply_add_rmsnorm(L.down, act8, residual, nw, s.rms_eps, ns)
             else:
-                h = self._all_reduce(L.down.forward_prequantized(act8, self.dtype))
-                if last:
-                    x = ops.rmsnorm(h, nw, s.rms_eps, residual=residual)
-                else:
-                    qx = ops.rmsnorm_fp8(h, nw, s.rms_eps, ns, residual=residual)
+                x, qx = self._row_parallel_add_norm(L.down, act8, residual, nw, ns)
         logits = torch.matmul(x, self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)
 

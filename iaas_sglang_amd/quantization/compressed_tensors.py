@@ -116,8 +116,9 @@ class CompressedTensorsLinearMethod(Fp8FusedDecodeMixin, LinearMethodBase):
         s = getattr(layer, "input_scale", None)
         return s if s is not None and s.numel() == 1 and layer.weight_scale.numel() == 1 else None
 
-    def apply_prequantized(self, layer, qx, out_dtype, bias=None):
-        return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1), out_dtype, bias)
+    def apply_prequantized(self, layer, qx, out_dtype, bias=None, out=None):
+        return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1), out_dtype,
+                            bias, out)
 
 
 class CompressedTensorsConfig(QuantizationConfig):

@@ -140,10 +140,11 @@ class Fp8LinearMethod(Fp8FusedDecodeMixin, LinearMethodBase):
         return s if s is not None and s.numel() == 1 else None
 
     def apply_prequantized(self, layer: torch.nn.Module, qx: torch.Tensor, out_dtype: torch.dtype,
-                           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`apply` minus the activation quantisation: qx is already fp8 with layer.input_scale."""
+                           bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`apply` minus the activation quantisation: qx is already fp8 with layer.input_scale.  `out`: write there
+        (e.g. the all-reduce staging buffer of a row-parallel linear)."""
         return ops.fp8_gemm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(-1),
-                            out_dtype, bias)
+                            out_dtype, bias, out)
 
     def __init__(self, quant_config: Fp8Config):
         self.quant_config = quant_config

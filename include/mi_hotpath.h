@@ -290,6 +290,21 @@ void* mi_ar_create(void** shared_ptrs /* [world], own entry = local pointer */, 
 int mi_ar_destroy(void* ctx);
 int mi_ar_error(void* ctx);                               /* 0 ok, 1 a barrier timed out */
 int mi_ar_all_reduce(void* ctx, const void* inp, void* out, int64_t bytes, int dtype, void* stream);
+/* The rank's own IPC-mapped staging buffer (max_bytes).  A producer that writes its output there and passes this
+ * pointer as `inp` skips the staging copy.
+ * replaces: register_buffer / get_graph_buffer_ipc_meta / register_graph_buffers, sgl_kernel_ops.h:58-68 with
+ * custom_all_reduce.py:387-412 (one persistent registered buffer instead of re-registration after capture). */
+void* mi_ar_staging(void* ctx);
+/* All-reduce of inp [rows, H] fused with its consumer: x32 = sum_ranks(inp) (rounded to T) + residual;
+ * residual <- x32 (in place, nullable); out = x32 * rsqrt(mean(x32^2) + eps) * weight (T, nullable); q_out (nullable)
+ * = fp8 e4m3fn of out with the static per-tensor *q_scale.  Bit-identical to mi_ar_all_reduce followed by
+ * mi_rmsnorm / mi_rmsnorm_fp8; the reduced tensor is never written.  bf16 / fp16; rows*H*2 <= max_bytes.
+ * replaces: tensor_model_parallel_all_reduce + RMSNorm, layers/communicator.py with
+ * layers/flashinfer_comm_fusion.py (fused allreduce + residual + rmsnorm) and layers/layernorm.py:128-146. */
+int mi_ar_all_reduce_add_rmsnorm(void* ctx, const void* inp, void* residual /* nullable, in/out */,
+                                 const void* weight, void* out /* nullable */, void* q_out /* nullable */,
+                                 const float* q_scale, int64_t rows, int64_t H, int64_t ldr, int64_t ldo, float eps,
+                                 int dtype, void* stream);
 
 /* ------------------------------------------ layer glue (SURVEY 8f "next" rows 1-2) */
 
