@@ -427,7 +427,9 @@ def main():
                                f"{'fp8 e4m3' if kv8 else 'bf16'} paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
-                   "all_reduce": None if tp == 1 else ("native-xgmi" if custom_ar is not None else "rccl"),
+                   "all_reduce": None if tp == 1 else (
+                       ("native-xgmi fused with add+rmsnorm+fp8 quant" if custom_ar.should_fuse_norm(B, shape.hidden, dtype)
+                        else "native-xgmi") if custom_ar is not None else "rccl"),
                    "kv_splits": kv_splits},
         "prefill": prefill,
         "ragged_decode_attention": ragged,
