@@ -31,6 +31,42 @@ class ForwardMetadata:
     work: Optional[torch.Tensor] = None             # ragged batches: (request, split) launch list, longest first
     custom_mask: Optional[torch.Tensor] = None      # TARGET_VERIFY: flat tree mask (triton_backend.py:253-260)
     mask_indptr: Optional[torch.Tensor] = None
+    # decode, sliding-window layers: the same fields over the last min(S, window + 1) keys of every request
+    # (window_kv_indptr / window_kv_indices / window_num_kv_splits of triton_backend.py:35-37)
+    window: Optional["ForwardMetadata"] = None
+
+
+class _GraphPlan:
+    """Device buffer {num_work, num_splits, split_chunk, - | work list} read by the captured decode launches, with the
+    rotating pinned staging it is rewritten from (an event guards reuse, so the host never waits unless it runs four
+    steps ahead of the device)."""
+
+    def __init__(self, cap: int, device):
+        self.cap = cap
+        self.buf = torch.zeros(4 + 2 * cap, dtype=torch.int32, device=device)
+        pin = torch.device(device).type == "cuda"
+        self.stage = [torch.zeros(4 + 2 * cap, dtype=torch.int32, pin_memory=pin) for _ in range(4)]
+        self.ev = [None] * len(self.stage)
+        self.i = 0
+
+    def write(self, splits: int, chunk: int, work: torch.Tensor):
+        n = work.shape[0]
+        i = self.i
+        self.i = (i + 1) % len(self.stage)
+        stage, ev = self.stage[i], self.ev[i]
+        if ev is not None:
+            ev.synchronize()
+        stage[0], stage[1], stage[2] = n, splits, chunk
+        stage[4: 4 + 2 * n] = work.reshape(-1)
+        self.buf[: 4 + 2 * n].copy_(stage[: 4 + 2 * n], non_blocking=True)
+        if stage.is_pinned():
+            ev = torch.cuda.Event()
+            ev.record()
+            self.ev[i] = ev
+
+    def views(self, cap: int):
+        assert cap <= self.cap
+        return self.buf[4: 4 + 2 * cap].view(cap, 2), self.buf[:4]
 
 
 class MiAttnBackend(AttentionBackend):
@@ -49,12 +85,14 @@ class MiAttnBackend(AttentionBackend):
         # --triton-attention-num-kv-splits (server_args.py:210) is reused as the split cap
         self.max_kv_splits = int(os.environ.get("MI_ATTN_MAX_KV_SPLITS",
                                                 getattr(sa, "triton_attention_num_kv_splits", 8) or 8))
-        if getattr(model_runner, "sliding_window_size", None):
-            raise NotImplementedError("MiAttnBackend: sliding-window models are not wired yet")
+        # triton_backend.py:63-68: layers with layer.sliding_window_size > -1 attend the last window + 1 keys
+        sw = getattr(model_runner, "sliding_window_size", None)
+        self.sliding_window_size = int(sw) if sw is not None and int(sw) > 0 else None
         self.skip_prefill = skip_prefill
         self.num_draft_tokens = getattr(sa, "speculative_num_draft_tokens", None)
         self.mask_indptr = torch.zeros(max_bs + 1, dtype=torch.int64, device=self.device)
         self.kv_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
+        self.window_kv_indptr = torch.zeros_like(self.kv_indptr) if self.sliding_window_size else None
         self.qo_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
         self.cu_count = max(ops.cu_count(), 1)
         self.forward_metadata: Optional[ForwardMetadata] = None
@@ -122,6 +160,25 @@ class MiAttnBackend(AttentionBackend):
         splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu)
         return splits, chunk, (work.to(self.device, non_blocking=True) if work is not None else None)
 
+    def _window_lens(self, seq_lens, seq_lens_cpu, seq_lens_sum: int, bs: int):
+        """update_sliding_window_buffer (triton_backend.py:927-955): the last min(S, window + 1) keys of every request.
+        Returns (device lens int64, device start int32, host lens or None, their sum or an upper bound of it)."""
+        w1 = self.sliding_window_size + 1
+        wl = torch.clamp(seq_lens[:bs], max=w1)
+        start = (seq_lens[:bs] - wl).to(torch.int32)
+        wl_cpu = torch.clamp(torch.as_tensor(seq_lens_cpu)[:bs], max=w1) if seq_lens_cpu is not None else None
+        wsum = int(wl_cpu.sum()) if wl_cpu is not None else min(seq_lens_sum, bs * w1)
+        return wl, start, wl_cpu, wsum
+
+    def _window_decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, seq_lens_cpu) -> ForwardMetadata:
+        wl, start, wl_cpu, wsum = self._window_lens(seq_lens, seq_lens_cpu, seq_lens_sum, bs)
+        indptr = ops.kv_indptr(wl, self.window_kv_indptr)
+        indices = torch.empty(max(wsum, 1), dtype=torch.int32, device=self.device)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], wl, indptr, indices, kv_start_idx=start)
+        splits, chunk, work = self._choose_split_plan(bs, wsum, wl_cpu)
+        return ForwardMetadata(indptr, indices, None, None, splits, self._workspace(bs, splits), split_chunk=chunk,
+                               work=work)
+
     def _workspace(self, bs: int, splits: int) -> Optional[torch.Tensor]:
         n = ops.decode_workspace_numel(bs, self.num_head, self.v_head_dim, splits)
         if n == 0:
@@ -163,6 +220,10 @@ class MiAttnBackend(AttentionBackend):
                                                           getattr(forward_batch, "seq_lens_cpu", None))
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, None, None, splits,
                                                     self._workspace(bs, splits), split_chunk=chunk, work=work)
+            if self.sliding_window_size:
+                self.forward_metadata.window = self._window_decode_metadata(
+                    bs, forward_batch.req_pool_indices, forward_batch.seq_lens, int(forward_batch.seq_lens_sum),
+                    getattr(forward_batch, "seq_lens_cpu", None))
         else:
             # extend / mixed: kv_indices cover the cached PREFIX only (triton_backend.py:302-321); the
             # host-side length lists avoid the reference's .item() syncs (:288,:320)
@@ -187,39 +248,39 @@ class MiAttnBackend(AttentionBackend):
                                                   device=self.device))
         n = ops.decode_workspace_numel(max_num_tokens, self.num_head, self.v_head_dim, self.max_kv_splits)
         self.cuda_graph_workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
-        cap = max_num_tokens * self.max_kv_splits
-        self.cuda_graph_plan_buf = torch.zeros(4 + 2 * cap, dtype=torch.int32, device=self.device)
-        pin = torch.device(self.device).type == "cuda"
-        self._plan_stage = [torch.zeros(4 + 2 * cap, dtype=torch.int32, pin_memory=pin) for _ in range(4)]
-        self._plan_stage_ev = [None] * len(self._plan_stage)
-        self._plan_stage_i = 0
+        self._gplan = _GraphPlan(max_num_tokens * self.max_kv_splits, self.device)
+        self.cuda_graph_plan_buf = self._gplan.buf
+        if self.sliding_window_size:
+            # triton_backend.py:373-381
+            wcap = max_num_tokens * min(self.max_context_len, self.sliding_window_size + 1)
+            self.cuda_graph_window_kv_indices = torch.zeros(wcap, dtype=torch.int32, device=self.device)
+            self._gplan_win = _GraphPlan(max_num_tokens * self.max_kv_splits, self.device)
 
-    def _write_graph_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu):
+    def _write_graph_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu, gplan=None):
         """Plan this replay on the host and ship {num_work, num_splits, split_chunk | work list} to the device buffer
-        the captured kernels read.  The pinned staging buffers rotate (an event guards reuse), so the copy is
-        asynchronous and the host never waits unless it runs four steps ahead of the device."""
+        the captured kernels read (one small async copy from rotating pinned buffers, no host sync)."""
         splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu, force_list=True)
-        n = work.shape[0]
-        assert splits <= self.max_kv_splits and n <= bs * self.max_kv_splits
-        i = self._plan_stage_i
-        self._plan_stage_i = (i + 1) % len(self._plan_stage)
-        stage, ev = self._plan_stage[i], self._plan_stage_ev[i]
-        if ev is not None:
-            ev.synchronize()
-        stage[0], stage[1], stage[2] = n, splits, chunk
-        stage[4: 4 + 2 * n] = work.reshape(-1)
-        self.cuda_graph_plan_buf[: 4 + 2 * n].copy_(stage[: 4 + 2 * n], non_blocking=True)
-        if stage.is_pinned():
-            ev = torch.cuda.Event()
-            ev.record()
-            self._plan_stage_ev[i] = ev
+        assert splits <= self.max_kv_splits and work.shape[0] <= bs * self.max_kv_splits
+        (gplan or self._gplan).write(splits, chunk, work)
 
-    def _graph_metadata(self, bs: int, kv_indptr) -> ForwardMetadata:
-        cap = bs * self.max_kv_splits
-        plan = self.cuda_graph_plan_buf[:4]
-        work = self.cuda_graph_plan_buf[4: 4 + 2 * cap].view(cap, 2)
-        return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, self.max_kv_splits,
-                               self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
+    def _graph_metadata(self, bs: int, kv_indptr, kv_indices=None, gplan=None) -> ForwardMetadata:
+        work, plan = (gplan or self._gplan).views(bs * self.max_kv_splits)
+        return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices if kv_indices is None else kv_indices, None, None,
+                               self.max_kv_splits, self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
+
+    def _graph_window(self, bs, req_pool_indices, seq_lens, seq_lens_sum, seq_lens_cpu) -> Optional[ForwardMetadata]:
+        """Capture and replay of the sliding-window set (update_sliding_window_buffer_cuda_graph,
+        triton_backend.py:958-984): indices into the persistent buffer, plan into its own device buffer."""
+        if not self.sliding_window_size:
+            return None
+        wl, start, wl_cpu, wsum = self._window_lens(seq_lens, seq_lens_cpu, seq_lens_sum, bs)
+        indptr = ops.kv_indptr(wl, self.window_kv_indptr)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], wl, indptr, self.cuda_graph_window_kv_indices,
+                       kv_start_idx=start)
+        if self.max_kv_splits > 1:
+            self._write_graph_plan(bs, wsum, wl_cpu, self._gplan_win)
+            return self._graph_metadata(bs, indptr, self.cuda_graph_window_kv_indices, self._gplan_win)
+        return ForwardMetadata(indptr, self.cuda_graph_window_kv_indices, None, None, 1, None)
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
                                                  forward_mode, spec_info):
@@ -236,6 +297,8 @@ class MiAttnBackend(AttentionBackend):
             self.forward_metadata = self._graph_metadata(bs, kv_indptr)
         else:
             self.forward_metadata = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, 1, None)
+        self.forward_metadata.window = self._graph_window(bs, req_pool_indices, seq_lens,
+                                                          bs * self.get_cuda_graph_seq_len_fill_value(), None)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
@@ -246,6 +309,7 @@ class MiAttnBackend(AttentionBackend):
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
         if self.max_kv_splits > 1:
             self._write_graph_plan(bs, int(seq_lens_sum), seq_lens_cpu)
+        self._graph_window(bs, req_pool_indices, seq_lens, int(seq_lens_sum), seq_lens_cpu)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # triton_backend.py:629 -- padded rows attend one key (slot 0 sink via req_to_token)
@@ -285,6 +349,11 @@ class MiAttnBackend(AttentionBackend):
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
+        lw = getattr(layer, "sliding_window_size", None)
+        if lw is not None and lw > -1:           # triton_backend.py:711-713
+            if md.window is None:
+                raise ValueError("sliding-window layer, but model_runner.sliding_window_size was not set")
+            md = md.window
         if k_buf.element_size() == 1:            # fp8 KV cache
             ks, vs = self._kv_scales(layer)
             q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)

@@ -576,3 +576,64 @@ def test_backend_ragged_decode_uses_work_list_and_matches_oracle():
     oa_f = oa.decode_fp32(q.view(-1, Hq, D), kc, vc, runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
                           fb.seq_lens.cpu(), scaling=D ** -0.5)
     torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), oa_f, atol=4e-3, rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_backend_sliding_window_decode_matches_oracle(graph):
+    """Sliding-window layers (layer.sliding_window_size = W > -1) decode over the last min(S, W + 1) keys
+    (triton_backend.py:186-205, 711-713); full-attention layers of the same model keep the whole sequence.  The
+    expectation is the oracle's extend form with its window mask (q_pos <= k_pos + W) for one new token."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype = H.LLAMA3_8B, torch.bfloat16
+    Hq, Hkv, D, W = 32, 8, 128, 100
+    trials = [[300, 17, 1500, 64, 101, 102], [2000, 2000, 2000, 2000, 2000, 2000], [1, 2, 3, 100, 101, 3000]]
+    bs = len(trials[0])
+    runner = H.make_runner(shape, max_reqs=8, ctx=4096, pool_tokens=13000, dtype=dtype, device=DEV, fill_kv=True)
+    runner.token_to_kv_pool = H.make_kv_pool(13000, 1, Hkv, D, dtype, DEV, fill_random=True)
+    runner.sliding_window_size = W
+    backend = MiAttnBackend(runner)
+    win_layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    win_layer.sliding_window_size = W
+    full_layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    pool = runner.token_to_kv_pool
+    g = torch.Generator().manual_seed(8)
+    rpi = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    seq_lens = torch.ones(bs, dtype=torch.int64, device=DEV)
+    q = torch.zeros(bs, Hq * D, dtype=dtype, device=DEV)
+    if graph:
+        backend.init_cuda_graph_state(bs, bs)
+        fbg = H.make_decode_batch(runner, backend, bs, 5, DEV, seed=1)
+        fbg.req_pool_indices, fbg.seq_lens = rpi, seq_lens
+        backend.init_forward_metadata_capture_cuda_graph(bs, bs, rpi, seq_lens, None, H.ForwardMode.DECODE, None)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            o_win_g = backend.forward(q, None, None, win_layer, fbg, save_kv_cache=False)
+            o_full_g = backend.forward(q, None, None, full_layer, fbg, save_kv_cache=False)
+    for t, lens in enumerate(trials):
+        fb = H.make_decode_batch(runner, backend, bs, 0, DEV, seed=20 + t, ragged=torch.tensor(lens))
+        qc = torch.randn(bs, Hq * D, generator=g).to(dtype)
+        q.copy_(qc)
+        if graph:
+            rpi.copy_(fb.req_pool_indices); seq_lens.copy_(fb.seq_lens)
+            backend.init_forward_metadata_replay_cuda_graph(bs, rpi, seq_lens, sum(lens), None, H.ForwardMode.DECODE,
+                                                            None, fb.seq_lens_cpu)
+            cg.replay()
+            torch.cuda.synchronize()
+            o_win, o_full = o_win_g.clone(), o_full_g.clone()
+        else:
+            backend.init_forward_metadata(fb)
+            md = backend.forward_metadata
+            assert md.window is not None and int(md.window.kv_indptr[bs]) == sum(min(L, W + 1) for L in lens)
+            o_win = backend.forward(q, None, None, win_layer, fb, save_kv_cache=False)
+            o_full = backend.forward(q, None, None, full_layer, fb, save_kv_cache=False)
+        kc, vc = pool.k_buffer[0].cpu(), pool.v_buffer[0].cpu()
+        r2t = runner.req_to_token_pool.req_to_token.cpu()
+        sl = torch.tensor(lens)
+        want_full = oa.decode_fp32(qc.view(bs, Hq, D), kc, vc, r2t, fb.req_pool_indices.cpu(), sl, scaling=D ** -0.5)
+        want_win = oa.extend_fp32(qc.view(bs, Hq, D), kc, vc, r2t, fb.req_pool_indices.cpu(), sl, sl - 1,
+                                  torch.ones(bs, dtype=torch.int64), scaling=D ** -0.5, causal=True, sliding_window=W)
+        torch.testing.assert_close(o_full.view(bs, Hq, D).cpu().float(), want_full, atol=4e-3, rtol=2 ** -7)
+        torch.testing.assert_close(o_win.view(bs, Hq, D).cpu().float(), want_win, atol=4e-3, rtol=2 ** -7)
+        assert not torch.allclose(want_win[2], want_full[2], atol=1e-2) or lens[2] <= W + 1   # the window really matters

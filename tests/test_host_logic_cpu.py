@@ -116,9 +116,13 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     with pytest.raises(ValueError):
         be.init_forward_metadata(fb)                          # verify without a tree mask / draft count: loud
     r = _fake_runner()
-    r.sliding_window_size = 4096
-    with pytest.raises(NotImplementedError):
-        ab.MiAttnBackend(r)
+    r.sliding_window_size = 100
+    bw = ab.MiAttnBackend(r)                                  # sliding-window models: last window + 1 keys per request
+    assert bw.sliding_window_size == 100 and bw.window_kv_indptr is not None
+    wl, start, wl_cpu, wsum = bw._window_lens(torch.tensor([5, 101, 102, 4000]), torch.tensor([5, 101, 102, 4000]), 4208, 4)
+    assert wl.tolist() == [5, 101, 101, 101] and start.tolist() == [0, 0, 1, 3899] and wsum == 308
+    assert start.dtype == torch.int32 and wl_cpu.tolist() == wl.tolist()
+    assert bw._window_lens(torch.tensor([5, 4000]), None, 4005, 2)[3] == 202     # no host lengths: an upper bound
 
 
 def test_register_is_a_noop_without_sglang():
