@@ -117,7 +117,8 @@ except Exception:  # ImportError or any of SGLang's own import-time failures
         """python/sglang/srt/layers/linear.py:111-149."""
 
     class UnquantizedLinearMethod(LinearMethodBase):
-        """Placeholder: skipped layers are handled by the reference's own class in a real install."""
+        """linear.py:152-193.  In a real install skipped / unquantised layers are handled by the reference's own class;
+        this stand-in does the same thing -- a plain library GEMM (F.linear -> hipBLASLt), not a hot-path kernel."""
 
         def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size,
                            output_size, params_dtype, **extra):
@@ -126,7 +127,7 @@ except Exception:  # ImportError or any of SGLang's own import-time failures
             layer.register_parameter("weight", w)
 
         def apply(self, layer, x, bias=None):
-            raise NotImplementedError("unquantized layers are outside this package's hot path")
+            return torch.nn.functional.linear(x, layer.weight, bias)
 
     class LinearBase(torch.nn.Module):
         """Marker base (python/sglang/srt/layers/linear.py:153)."""

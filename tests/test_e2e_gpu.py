@@ -13,8 +13,13 @@ from oracle import quant as oq  # noqa: E402
 DEV = "cuda"
 
 
-def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_lens, pre, ext, loc, decode):
-    """Same layer order as harness.LlamaStack.forward, every op from oracle/ (CPU)."""
+def _fp8_lin(x, W, key):
+    return oq.fp8_linear(x, W[key + "_w"], W[key + "_s"], W.get(key + "_i"))
+
+
+def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_lens, pre, ext, loc, decode, lin=_fp8_lin):
+    """Same layer order as harness.LlamaStack.forward, every op from oracle/ (CPU); `lin(x, W, key)` is the
+    oracle form of the stack's linear method."""
     D, Hq, Hkv = shape.head_dim, shape.num_heads, shape.num_kv_heads
     cache = oe.rope_cos_sin_cache(D, shape.context_len, shape.rope_theta)
     residual = None
@@ -24,7 +29,7 @@ def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_len
             x = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps)
         else:
             x, residual = oe.rmsnorm(hidden, W["input_norm"], shape.rms_eps, residual)
-        qkv = oq.fp8_linear(x, W["qkv_w"], W["qkv_s"], W.get("qkv_i"))
+        qkv = lin(x, W, "qkv")
         q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
         q, k = oe.rope_neox(positions, q.contiguous(), k.contiguous(), cache, D)
         k3, v3 = k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D)
@@ -32,10 +37,10 @@ def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_len
             a = oa.forward_decode(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, loc, Hq, Hkv, D ** -0.5)
         else:
             a = oa.forward_extend(q, k3, v3, kc[li], vc[li], r2t, rpi, seq_lens, pre, ext, loc, Hq, Hkv, D ** -0.5)
-        hidden = oq.fp8_linear(a, W["o_w"], W["o_s"], W.get("o_i"))
+        hidden = lin(a, W, "o")
         x, residual = oe.rmsnorm(hidden, W["post_norm"], shape.rms_eps, residual)
-        gu = oq.fp8_linear(x, W["gu_w"], W["gu_s"], W.get("gu_i"))
-        hidden = oq.fp8_linear(oe.silu_and_mul(gu), W["down_w"], W["down_s"], W.get("down_i"))
+        gu = lin(x, W, "gu")
+        hidden = lin(oe.silu_and_mul(gu), W, "down")
     x, _ = oe.rmsnorm(hidden, stack_w["final_norm"], shape.rms_eps, residual)
     return (x.float() @ stack_w["lm_head"].float().t())
 
@@ -157,3 +162,103 @@ def test_backend_graph_capture_replay_matches_eager(ctx, trials):
         eager_backend.init_forward_metadata(fb2)
         want = eager_backend.forward(q, k, v, layer, fb2)     # KV write is idempotent (same k,v,slots)
         torch.testing.assert_close(got.float(), want.float(), atol=4e-3, rtol=2 ** -7)
+
+
+def _extend_then_decode(stack, runner, backend, shape, dtype, W, lin, prefix, extend, tol, decode_steps=2):
+    """Ragged EXTEND (with cached prefixes) and then decode steps through the plugin surfaces vs the oracle stack."""
+    from iaas_sglang_amd import harness as H
+    g = torch.Generator().manual_seed(0)
+    pool = runner.token_to_kv_pool
+    fb = H.make_extend_batch(runner, backend, prefix, extend, DEV, seed=1)
+    hidden = torch.randn(sum(extend), shape.hidden, generator=g).to(dtype)
+    kc = [b.cpu().clone() for b in pool.k_buffer]          # prefixes are already cached (random rows)
+    vc = [b.cpu().clone() for b in pool.v_buffer]
+    backend.init_forward_metadata(fb)
+    logits = stack.forward(hidden.to(DEV), fb.positions, fb, backend)
+    r2t = runner.req_to_token_pool.req_to_token.cpu()
+    ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc, r2t, fb.req_pool_indices.cpu(),
+                          fb.seq_lens.cpu(), fb.extend_prefix_lens.cpu(), fb.extend_seq_lens.cpu(),
+                          fb.out_cache_loc.cpu(), decode=False, lin=lin)
+    assert float((logits.float().cpu() - ref).abs().max()) < tol
+    lens = [p + e for p, e in zip(prefix, extend)]
+    next_slot = int(runner.req_to_token_pool.req_to_token.max()) + 1
+    for step in range(decode_steps):
+        lens = [L + 1 for L in lens]
+        B = len(lens)
+        loc = torch.arange(next_slot, next_slot + B, dtype=torch.int64)
+        next_slot += B
+        for i in range(B):
+            runner.req_to_token_pool.req_to_token[i, lens[i] - 1] = int(loc[i])
+        fb.forward_mode = H.ForwardMode.DECODE
+        fb.seq_lens = torch.tensor(lens, dtype=torch.int64, device=DEV)
+        fb.seq_lens_cpu = torch.tensor(lens, dtype=torch.int64)
+        fb.seq_lens_sum = sum(lens)
+        fb.out_cache_loc = loc.to(DEV)
+        fb.positions = (fb.seq_lens - 1)
+        hidden = torch.randn(B, shape.hidden, generator=g).to(dtype)
+        backend.init_forward_metadata(fb)
+        logits = stack.forward(hidden.to(DEV), fb.positions, fb, backend)
+        ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc,
+                              runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
+                              fb.seq_lens.cpu(), None, None, loc, decode=True, lin=lin)
+        assert float((logits.float().cpu() - ref).abs().max()) < tol
+    for li in range(shape.layers):      # the pool holds exactly what the oracle wrote (same rows, rounding aside)
+        torch.testing.assert_close(pool.k_buffer[li].cpu().float(), kc[li].float(), atol=tol, rtol=2e-2)
+
+
+def test_tiny_llama_bf16_ragged_extend_with_prefix_then_decode():
+    """Config C2 in miniature: bf16 linears (library GEMM, not ours), OUR paged-KV extend + decode attention on a
+    ragged batch with cached prefixes; glue kernels ours."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd._compat import UnquantizedLinearMethod
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype = H.TINY, torch.bfloat16
+    runner = H.make_runner(shape, max_reqs=8, ctx=512, pool_tokens=1200, dtype=dtype, device=DEV, fill_kv=True)
+    backend = MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, UnquantizedLinearMethod, dtype, DEV, weight_range=0.05, weights_cpu_seeded=True)
+    W = {"layers": [], "final_norm": stack.final_norm.cpu(), "lm_head": stack.lm_head.cpu()}
+    for L in stack.layers:
+        d = {"input_norm": L.input_norm.cpu(), "post_norm": L.post_norm.cpu()}
+        for key, lin in (("qkv", L.qkv), ("o", L.o), ("gu", L.gate_up), ("down", L.down)):
+            d[key + "_w"] = lin.weight.detach().cpu()
+        W["layers"].append(d)
+
+    def lin(x, Wl, key):       # F.linear in fp32, one rounding to bf16 (what a bf16 GEMM with fp32 accumulation gives)
+        return (x.float() @ Wl[key + "_w"].float().t()).to(dtype)
+
+    _extend_then_decode(stack, runner, backend, shape, dtype, W, lin, prefix=[64, 0, 200, 17, 0],
+                        extend=[1, 37, 128, 5, 300], tol=5e-2)
+
+
+def test_tiny_llama_awq_extend_then_decode(monkeypatch):
+    """Config C4 in miniature: AWQ int4 g128 linears (fused dequant GEMM), fp16 activations, through
+    AWQConfig.get_quant_method -> AWQLinearMethod, vs the oracle's awq_dequantize + matmul."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import AWQConfig
+    shape, dtype = H.TINY, torch.float16
+    cfg = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    ckpt = []
+    orig = H.LlamaStack._init_linear
+
+    def recording_init(lin, dummy):          # keep the checkpoint-layout tensors: the method repacks them afterwards
+        orig(lin, dummy)
+        ckpt.append({k: p.detach().cpu().clone() for k, p in lin.named_parameters()})
+
+    monkeypatch.setattr(H.LlamaStack, "_init_linear", staticmethod(recording_init))
+    runner = H.make_runner(shape, max_reqs=8, ctx=512, pool_tokens=1200, dtype=dtype, device=DEV, fill_kv=True)
+    backend = MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, DEV, weights_cpu_seeded=True)
+    assert type(stack.layers[0].qkv.quant_method).__name__ == "AWQLinearMethod" and len(ckpt) == 4 * shape.layers
+    W = {"layers": [], "final_norm": stack.final_norm.cpu(), "lm_head": stack.lm_head.cpu()}
+    for li, L in enumerate(stack.layers):
+        d = {"input_norm": L.input_norm.cpu(), "post_norm": L.post_norm.cpu()}
+        for j, key in enumerate(("qkv", "o", "gu", "down")):
+            d[key] = ckpt[4 * li + j]
+        W["layers"].append(d)
+
+    def lin(x, Wl, key):
+        c = Wl[key]
+        return oq.awq_linear(x, c["qweight"], c["scales"], c["qzeros"])
+
+    _extend_then_decode(stack, runner, backend, shape, dtype, W, lin, prefix=[0, 33, 0], extend=[37, 5, 64], tol=5e-2)
