@@ -83,7 +83,10 @@ def _synthetic(B, Hq, Hkv, D, lens, dtype, seed=0, scattered=True):
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (8, 8, 128, torch.float16),
-                                            (12, 12, 64, torch.float16), (14, 2, 128, torch.bfloat16)])
+                                            (12, 12, 64, torch.float16), (14, 2, 128, torch.bfloat16),
+                                            (8, 1, 128, torch.bfloat16),      # C5 per rank: Llama-3-70B at TP=8
+                                            (4, 1, 128, torch.bfloat16),      # C3 at TP=8
+                                            (32, 32, 128, torch.float16)])    # C4: Llama-2-7B (MHA)
 def test_decode_ragged_vs_oracle(Hq, Hkv, D, dtype):
     lens = [1, 2, 15, 16, 17, 31, 32, 33, 100, 511, 512, 700]
     q, k, v, r2t, rpi, sl = _synthetic(len(lens), Hq, Hkv, D, lens, dtype, seed=1)
