@@ -751,8 +751,24 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   }
 }
 
+// Decode batches beyond 128 rows (graph batch sizes up to 512, C5's batch 256): the 256 x 256 tile kernel would put
+// cdiv(M,256) * cdiv(N,256) workgroups on the chip -- 16 for a 4096-wide o/down projection at M = 256, each
+// streaming (256 + 256) x K bytes through ONE CU's ~42 GB/s LDS-DMA path (measured: 199 us for 256 x 4096 x 14336,
+// against 24 us at M = 128).  Until the tile grid fills the chip it is cheaper to run the x-stationary decode
+// kernel once per 128-row chunk: every chunk streams the weights again (the second pass mostly from the 256-MB
+// Infinity Cache), all 256 CUs busy each time.  Cost model in us, from the measured rates.
+static bool mid_m_chunked(int64_t M, int64_t N, int64_t K) {
+  if (M <= 128 || M > 1024 || K % 128 != 0) return false;
+  const double tiles = (double)(cdiv64(M, 256) * cdiv64(N, 256));
+  const double t_tile = (double)cdiv64((int64_t)tiles, 256) * (512.0 * (double)K / 42e3) + 5.0;
+  const double t_chunk = (double)cdiv64(M, 128) * ((double)N * (double)K / 3.5e6 + 10.0);
+  return t_chunk < t_tile;
+}
+
 extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M > 128 || M <= 0 || K % 128 != 0) return 0;
+  if (M <= 0 || K % 128 != 0) return 0;
+  if (M > 128 && !mid_m_chunked(M, N, K)) return 0;
+  if (M > 128) M = 128;                      // the chunks run one after the other through the same slabs
   int S, spw;
   xs_plan(N, K, &S, &spw);
   return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
@@ -923,6 +939,17 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     else if (p.M <= 32) launch_skinny<OutT, 2>(p, st);
     else if (p.M <= 64) launch_skinny<OutT, 4>(p, st);
     else launch_skinny<OutT, 8>(p, st);
+    return;
+  }
+  if (mid_m_chunked(p.M, p.N, p.K)) {  // decode batches of 129..1024 rows on narrow outputs: 128-row chunks
+    for (int64_t m0 = 0; m0 < p.M; m0 += 128) {
+      GemmParams q = p;
+      q.M = p.M - m0 < 128 ? p.M - m0 : 128;
+      q.a = p.a + m0 * p.lda;
+      q.out = (char*)p.out + m0 * p.ldo * (int64_t)sizeof(OutT);
+      if (p.sa_row) q.sa = p.sa + m0;
+      launch_fp8_gemm<OutT>(q, st, workspace, workspace_bytes);
+    }
     return;
   }
   if (p.K % 128 == 0) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel

@@ -75,7 +75,8 @@ def test_fp8_gemm_golden(golden_quant, name):
                                    (64, 4096, 14336), (300, 520, 1024), (512, 256, 256), (257, 1000, 512),
                                    (2048, 6144, 4096),
                                    # C5 per rank (Llama-3-70B, TP=8, batch 256): qkv, o, gate_up, down
-                                   (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584)])
+                                   (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584),
+                                   (136, 4096, 4096), (500, 4096, 2048)])          # 128-row chunks: 128 + 8, 3 x 128 + 116
 @pytest.mark.parametrize("modes", ["tt", "rr", "rt"])
 def test_fp8_gemm_random(M, N, K, modes):
     o_ = ops()
