@@ -240,7 +240,12 @@ __global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __r
 }
 
 // ============================================================================ public entry points
+// Batches beyond 128 rows (graph batch sizes up to 512, C5's batch 256) run the same fused pair once per 128-row
+// chunk, through the same slabs: every output row is produced exactly as in a <= 128-row call on its chunk.
+#define FUSED_MAX_M 512
+#define FUSED_CHUNK 128
 extern "C" int64_t mi_fp8_gemm_fused_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M > FUSED_CHUNK && M <= FUSED_MAX_M) M = FUSED_CHUNK;
   const int S = mi_fp8_gemm_plan_splits(M, N, K);
   return S > 0 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
 }
@@ -251,7 +256,7 @@ extern "C" int64_t mi_fp8_gemm_fused_workspace_bytes(int64_t M, int64_t N, int64
   MI_CHECK_ARG(a && b_nk && scale_a && scale_b);                                                          \
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);                                                     \
   const int S = mi_fp8_gemm_plan_splits(M, N, K);                                                         \
-  if (S <= 0) MI_FAIL(MI_ERR_UNSUPPORTED, NAME ": decode shapes only (M <= 128, K %% 128 == 0)");         \
+  if (S <= 0) MI_FAIL(MI_ERR_UNSUPPORTED, NAME ": decode shapes only (M <= 512, K %% 128 == 0)");         \
   const int64_t need = (int64_t)S * M * N * (int64_t)sizeof(float);                                       \
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))                                \
     MI_FAIL(MI_ERR_INVALID, NAME ": workspace of mi_fp8_gemm_fused_workspace_bytes() = %lld bytes needed", (long long)need)
@@ -261,6 +266,18 @@ extern "C" int mi_fp8_gemm_add_rmsnorm_fp8(const void* a, const void* b_nk, cons
                                            const float* q_scale, int64_t M, int64_t N, int64_t K, int64_t lda,
                                            int64_t ldb, float eps, int dtype, void* workspace,
                                            int64_t workspace_bytes, void* stream) {
+  if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
+    MI_CHECK_ARG(a && b_nk && (out || q_out));
+    const int64_t es = 2;   // bf16 / fp16
+    for (int64_t m0 = 0; m0 < M; m0 += FUSED_CHUNK) {
+      const int rc = mi_fp8_gemm_add_rmsnorm_fp8(
+          (const char*)a + m0 * lda, b_nk, scale_a, scale_b, residual ? (char*)residual + m0 * N * es : nullptr,
+          norm_weight, out ? (char*)out + m0 * N * es : nullptr, q_out ? (char*)q_out + m0 * N : nullptr, q_scale,
+          M - m0 < FUSED_CHUNK ? M - m0 : FUSED_CHUNK, N, K, lda, ldb, eps, dtype, workspace, workspace_bytes, stream);
+      if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+  }
   FUSED_PROLOGUE("mi_fp8_gemm_add_rmsnorm_fp8");
   MI_CHECK_ARG(norm_weight && (out || q_out) && (!q_out || q_scale));
   if (N % 8 != 0 || N > 256 * 8 * 8) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_add_rmsnorm_fp8: N must be a multiple of 8, <= 16384");
@@ -277,6 +294,18 @@ extern "C" int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const f
                                         int64_t lda, int64_t ldb, int64_t ldq, int64_t cache_stride_k,
                                         int64_t cache_stride_v, int dtype, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
+  if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
+    MI_CHECK_ARG(a && b_nk && positions && q_out && loc);
+    for (int64_t m0 = 0; m0 < M; m0 += FUSED_CHUNK) {
+      const int rc = mi_fp8_gemm_rope_kvwrite(
+          (const char*)a + m0 * lda, b_nk, scale_a, scale_b, positions ? positions + m0 : nullptr, cos_sin_cache,
+          q_out ? (char*)q_out + m0 * ldq * 2 : nullptr, k_cache, v_cache, loc ? loc + m0 : nullptr,
+          M - m0 < FUSED_CHUNK ? M - m0 : FUSED_CHUNK, num_q_heads, num_kv_heads, head_dim, K, lda, ldb, ldq,
+          cache_stride_k, cache_stride_v, dtype, workspace, workspace_bytes, stream);
+      if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+  }
   const int64_t N = (num_q_heads + 2 * num_kv_heads) * head_dim;
   FUSED_PROLOGUE("mi_fp8_gemm_rope_kvwrite");
   MI_CHECK_ARG(positions && cos_sin_cache && q_out && k_cache && v_cache && loc && num_q_heads > 0 && num_kv_heads > 0);
@@ -294,6 +323,16 @@ extern "C" int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const f
                                         int64_t lda, int64_t ldb, int dtype, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
   MI_CHECK_ARG(I > 0 && q_out && q_scale);
+  if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
+    MI_CHECK_ARG(a && b_nk);
+    for (int64_t m0 = 0; m0 < M; m0 += FUSED_CHUNK) {
+      const int rc = mi_fp8_gemm_silu_mul_fp8((const char*)a + m0 * lda, b_nk, scale_a, scale_b, (char*)q_out + m0 * I,
+                                              q_scale, M - m0 < FUSED_CHUNK ? M - m0 : FUSED_CHUNK, I, K, lda, ldb,
+                                              dtype, workspace, workspace_bytes, stream);
+      if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+  }
   if (M > 0 && a && b_nk && scale_a && scale_b) {   // in-kernel epilogue when the GEMM needs no split-K
     const int rc = mi_fp8_gemm_silu_epilogue(a, b_nk, scale_a, scale_b, q_out, q_scale, M, I, K, lda, ldb, dtype, stream);
     if (rc <= 0) return rc;

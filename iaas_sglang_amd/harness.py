@@ -248,7 +248,7 @@ class LlamaStack:
     def _fused_decode_ok(self, hidden, fb):
         if not (LlamaStack.fuse_decode_layer and Linear.fuse_producer_quant) or Linear.calibrating:
             return False
-        if not fb.forward_mode.is_decode() or hidden.shape[0] > 128:
+        if not fb.forward_mode.is_decode() or hidden.shape[0] > 512:
             return False
         M = hidden.shape[0]
         for L in self.layers:

@@ -478,7 +478,7 @@ def decode_attention_fp8kv(q: torch.Tensor, k_buf8: torch.Tensor, v_buf8: torch.
 def _fused_ws(M: int, N: int, K: int, device):
     nbytes = lib.mi_fp8_gemm_fused_workspace_bytes(M, N, K)
     if nbytes <= 0:
-        raise MiHotpathError(f"fused FP8 linear: decode shapes only (M={M} <= 128, K={K} % 128 == 0)")
+        raise MiHotpathError(f"fused FP8 linear: decode shapes only (M={M} <= 512, K={K} % 128 == 0)")
     return _gemm_workspace(nbytes, device), nbytes
 
 

@@ -108,7 +108,7 @@ class Fp8FusedDecodeMixin:
     def fused_decode_ok(layer: torch.nn.Module, M: int) -> bool:
         s = getattr(layer, "input_scale", None)
         K = layer.weight.shape[0]
-        return (s is not None and s.numel() == 1 and layer.weight_scale.numel() == 1 and 0 < M <= 128
+        return (s is not None and s.numel() == 1 and layer.weight_scale.numel() == 1 and 0 < M <= 512
                 and K % 128 == 0 and getattr(layer, "bias", None) is None)
 
     def apply_add_rmsnorm(self, layer, qx, residual, norm_weight, eps, next_scale=None, want_out=False):

@@ -341,7 +341,8 @@ int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx,
 
 /* ------------------------- decode-shaped FP8 linears fused with their consumer
  *
- * M <= 128, K % 128 == 0, per-tensor scales.  The GEMM leaves raw fp32 split-K partials in `workspace`
+ * M <= 512 (run per 128-row chunk through the same workspace; every row comes out as from a call on its chunk),
+ * K % 128 == 0, per-tensor scales.  The GEMM leaves raw fp32 split-K partials in `workspace`
  * (mi_fp8_gemm_fused_workspace_bytes(M,N,K) bytes, 16-byte aligned) and ONE consumer kernel sums them,
  * applies the GEMM epilogue x = round_T(acc * sa * sb) and the next op(s) of the decoder layer.  Every
  * rounding of the unfused call sequence is reproduced: results are bit-identical to it (tests/test_fused_gpu.py).

@@ -122,6 +122,59 @@ def test_decode_attention_fp8out_bit_identical(B, Hq, Hkv, D, splits, dtype):
     assert torch.equal(_bits(q1), _bits(o8)) and torch.equal(_bits(q1), _bits(o8b))
 
 
+@pytest.mark.parametrize("M", [129, 256, 300, 512])
+def test_fused_forms_beyond_128_rows_equal_the_per_chunk_sequence(M):
+    """Decode batches of 129..512 rows (graph batch sizes; C5 = batch 256) run the fused pair once per 128-row
+    chunk: every row must come out exactly as from the unfused sequence applied to its chunk."""
+    from iaas_sglang_amd import harness as H, ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M)
+    chunks = [(m0, min(M, m0 + 128)) for m0 in range(0, M, 128)]
+    # o/down: GEMM -> add -> RMSNorm -> fp8
+    N, K = 4096, 1024
+    qx, w, xs, ws = _fp8_operands(M, N, K, g)
+    res = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(DEV)
+    qscale = torch.tensor([0.02], device=DEV)
+    r1, r2 = res.clone(), res.clone()
+    outs, qs = [], []
+    for a, b in chunks:
+        y = ops.fp8_gemm(qx[a:b], w, xs, ws, dtype)
+        o = ops.rmsnorm(y, nw, 1e-5, residual=r1[a:b])
+        outs.append(o); qs.append(ops.fp8_quant_per_tensor(o, qscale)[0])
+    out2, q2 = ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, r2, nw, 1e-5, qscale, want_out=True)
+    assert torch.equal(_bits(torch.cat(outs)), _bits(out2)) and torch.equal(_bits(torch.cat(qs)), _bits(q2))
+    assert torch.equal(_bits(r1), _bits(r2))
+    # qkv: GEMM -> RoPE -> q + KV-pool rows
+    Hq, Hkv, D, K = 8, 2, 128, 512
+    qx, w, xs, ws = _fp8_operands(M, (Hq + 2 * Hkv) * D, K, g)
+    slots = 2 * M + 1
+    cache = H.rope_cache(D, 4096, 10000.0, DEV)
+    pos = torch.randint(0, 4096, (M,), generator=g).to(DEV)
+    loc = (torch.randperm(slots - 1, generator=g)[:M] + 1).to(DEV)
+    kc1 = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    vc1 = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    q1 = []
+    for a, b in chunks:
+        qkv = ops.fp8_gemm(qx[a:b], w, xs, ws, dtype)
+        qq, kk, vv = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+        ops.rope_neox_(qq, kk, pos[a:b], cache, D)
+        ops.kv_write(kc1, vc1, loc[a:b], kk, vv)
+        q1.append(qq.contiguous())
+    q2 = ops.fp8_gemm_rope_kvwrite(qx, w, xs, ws, pos, cache, kc2, vc2, loc, Hq, Hkv, D)
+    assert torch.equal(_bits(torch.cat(q1)), _bits(q2))
+    assert torch.equal(_bits(kc1), _bits(kc2)) and torch.equal(_bits(vc1), _bits(vc2))
+    # gate_up: both routes (in-kernel epilogue at I = 14336, slab consumer at I = 512)
+    for I, K in ((14336, 512), (512, 256)):
+        qx, w, xs, ws = _fp8_operands(M, 2 * I, K, g, amp=2.0)
+        qscale = torch.tensor([0.05], device=DEV)
+        q1 = torch.cat([ops.silu_and_mul_fp8(ops.fp8_gemm(qx[a:b], w, xs, ws, dtype), qscale) for a, b in chunks])
+        q2 = ops.fp8_gemm_silu_mul(qx, w, xs, ws, qscale, dtype)
+        assert torch.equal(_bits(q1), _bits(q2))
+    torch.cuda.synchronize()
+
+
 def _decode_logits(stack, runner, backend, fb, hidden, fused):
     from iaas_sglang_amd import harness as H
     H.LlamaStack.fuse_decode_layer = fused
@@ -172,7 +225,7 @@ def test_fused_entry_points_reject_bad_arguments():
     from iaas_sglang_amd import ops
     from iaas_sglang_amd._lib import MiHotpathError
     g = torch.Generator().manual_seed(0)
-    qx, w, xs, ws = _fp8_operands(200, 256, 256, g)          # M > 128: not a decode shape
+    qx, w, xs, ws = _fp8_operands(600, 256, 256, g)          # M > 512: not a decode shape
     with pytest.raises(MiHotpathError):
         ops.fp8_gemm_silu_mul(qx, w, xs, ws, torch.tensor([0.05], device=DEV), torch.bfloat16)
     qx, w, xs, ws = _fp8_operands(8, 256, 192, g)            # K % 128 != 0
