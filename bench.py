@@ -418,7 +418,9 @@ def main():
         except Exception as e:   # informational only
             ragged = {"error": f"{type(e).__name__}: {e}"}
     result = {
-        "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)" + (" [variant: fp8 KV cache]" if kv8 else ""),
+        "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)" + (" [variant: fp8 KV cache]" if kv8 else "")
+                  + ("" if (B, S, a.layers) == (128, 2048, 0) else
+                     f" [variant: batch {B}, KV seq {S}" + (f", {a.layers} layers" if a.layers else "") + "]"),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), " + ("fp8 e4m3" if kv8 else "bf16") + " KV/f32 softmax (attention)",
