@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  static_assert(D == 3 || D == 4, "wait_phase enumerates up to 3 phases in flight");
+  static_assert(D >= 2 && D <= 4, "wait_phase enumerates up to 3 phases in flight");
 
   if (ph0 < ph1) {
 #pragma unroll
@@ -739,6 +739,10 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   const int fs = partial ? 1 : 0;
   static const int split = xs_env("MI_GEMM_XS_SPLIT", 1);
   static const int deep = xs_env("MI_GEMM_XD", 1);
+  if constexpr (MT == 16) {
+    // 129..256 rows in one pass over the weights: 48-KiB stages (x 32 KiB + weights 16 KiB), ring of 3
+    fp8_gemm_xd_kernel<OutT, 16, 0, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
+  } else
   if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && deep) fp8_gemm_xd_kernel<OutT, MT, 0, 4><<<grid, 512, xd_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
@@ -757,18 +761,29 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
 // against 24 us at M = 128).  Until the tile grid fills the chip it is cheaper to run the x-stationary decode
 // kernel once per 128-row chunk: every chunk streams the weights again (the second pass mostly from the 256-MB
 // Infinity Cache), all 256 CUs busy each time.  Cost model in us, from the measured rates.
+// Decode batches beyond 128 rows (graph batch sizes up to 512, C5's batch 256): the 256 x 256 tile kernel would put
+// cdiv(M,256) * cdiv(N,256) workgroups on the chip -- 16 for a 4096-wide o/down projection at M = 256, each
+// streaming (256 + 256) x K bytes through ONE CU's ~42 GB/s LDS-DMA path (measured: 199 us for 256 x 4096 x 14336,
+// against 24 us at M = 128).  Until the tile grid fills the chip it is cheaper to run the x-stationary decode
+// kernel once per chunk of rows, all 256 CUs busy each time.  Cost model in us, from the measured rates.
+// rows one pass of the decode kernels takes: 256 with the 8-wave deep-ring kernel (MT = 16), else 128
+MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N) {
+  static const int deep = xs_env("MI_GEMM_XD", 1), wide = xs_env("MI_GEMM_XD16", 1);
+  return (xs_waves(N) == 8 && deep && wide) ? 256 : 128;
+}
 static bool mid_m_chunked(int64_t M, int64_t N, int64_t K) {
   if (M <= 128 || M > 1024 || K % 128 != 0) return false;
+  const int64_t rows = mi_fp8_gemm_partial_max_rows(N);
   const double tiles = (double)(cdiv64(M, 256) * cdiv64(N, 256));
   const double t_tile = (double)cdiv64((int64_t)tiles, 256) * (512.0 * (double)K / 42e3) + 5.0;
-  const double t_chunk = (double)cdiv64(M, 128) * ((double)N * (double)K / 3.5e6 + 10.0);
+  const double t_chunk = (double)cdiv64(M, rows) * ((double)N * (double)K / 3.5e6 + 10.0) * (rows == 256 ? 1.5 : 1.0);
   return t_chunk < t_tile;
 }
 
 extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || K % 128 != 0) return 0;
   if (M > 128 && !mid_m_chunked(M, N, K)) return 0;
-  if (M > 128) M = 128;                      // the chunks run one after the other through the same slabs
+  if (M > mi_fp8_gemm_partial_max_rows(N)) M = mi_fp8_gemm_partial_max_rows(N);   // chunks reuse the same slabs
   int S, spw;
   xs_plan(N, K, &S, &spw);
   return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
@@ -919,7 +934,9 @@ template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_
 
 template <typename OutT>
 static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
-  if (p.M <= 128 && p.K % 128 == 0) {  // decode shapes: x-stationary, weights streamed once
+  const int64_t pass_rows = p.M > 128 && p.M <= 256 && p.K % 128 == 0 ? mi_fp8_gemm_partial_max_rows(p.N) : 128;
+  if (p.M <= pass_rows && p.K % 128 == 0 && (p.M <= 128 || mid_m_chunked(p.M, p.N, p.K))) {
+    // decode shapes: x-stationary, weights streamed once
     int S, spw;
     xs_plan(p.N, p.K, &S, &spw);
     const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
@@ -931,7 +948,8 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st);
     else if (p.M <= 32) launch_xs<OutT, 2>(p, slab, S, spw, st);
     else if (p.M <= 64) launch_xs<OutT, 4>(p, slab, S, spw, st);
-    else launch_xs<OutT, 8>(p, slab, S, spw, st);
+    else if (p.M <= 128) launch_xs<OutT, 8>(p, slab, S, spw, st);
+    else launch_xs<OutT, 16>(p, slab, S, spw, st);
     return;
   }
   if (p.M <= 128) {  // K % 128 != 0: fragment-streaming kernel
@@ -941,10 +959,11 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     else launch_skinny<OutT, 8>(p, st);
     return;
   }
-  if (mid_m_chunked(p.M, p.N, p.K)) {  // decode batches of 129..1024 rows on narrow outputs: 128-row chunks
-    for (int64_t m0 = 0; m0 < p.M; m0 += 128) {
+  if (mid_m_chunked(p.M, p.N, p.K)) {  // decode batches of 129..1024 rows on narrow outputs: chunks of rows
+    const int64_t rows = mi_fp8_gemm_partial_max_rows(p.N);
+    for (int64_t m0 = 0; m0 < p.M; m0 += rows) {
       GemmParams q = p;
-      q.M = p.M - m0 < 128 ? p.M - m0 : 128;
+      q.M = p.M - m0 < rows ? p.M - m0 : rows;
       q.a = p.a + m0 * p.lda;
       q.out = (char*)p.out + m0 * p.ldo * (int64_t)sizeof(OutT);
       if (p.sa_row) q.sa = p.sa + m0;
@@ -997,7 +1016,7 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
 // ---- split-K partial form: raw fp32 accumulators, no epilogue; a fused consumer (fused_glue.hip)
 // sums the slabs and applies scales / residual / norm / rope itself.
 MI_INTERNAL int mi_fp8_gemm_plan_splits(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || M > 128 || K % 128 != 0) return 0;   // 0: the partial form does not apply
+  if (M <= 0 || M > mi_fp8_gemm_partial_max_rows(N) || K % 128 != 0) return 0;   // 0: the partial form does not apply
   int S, ppw;
   xs_plan(N, K, &S, &ppw);
   return S;
@@ -1005,7 +1024,7 @@ MI_INTERNAL int mi_fp8_gemm_plan_splits(int64_t M, int64_t N, int64_t K) {
 
 MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slabs, int64_t M, int64_t N, int64_t K,
                                    int64_t lda, int64_t ldb, void* stream) {
-  MI_CHECK_ARG(a && b_nk && slabs && M > 0 && M <= 128 && N > 0 && K > 0);
+  MI_CHECK_ARG(a && b_nk && slabs && M > 0 && N > 0 && K > 0 && M <= mi_fp8_gemm_partial_max_rows(N));
   if (K % 128 != 0 || lda % 16 != 0 || ldb % 16 != 0 || N % 4 != 0)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_partial: need K%%128==0, N%%4==0, lda/ldb%%16==0");
   MI_CHECK_ARG((((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)slabs) & 15) == 0);
@@ -1018,7 +1037,8 @@ MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slab
   if (M <= 16) launch_xs<bf16_t, 1>(p, slabs, S, ppw, st, true);
   else if (M <= 32) launch_xs<bf16_t, 2>(p, slabs, S, ppw, st, true);
   else if (M <= 64) launch_xs<bf16_t, 4>(p, slabs, S, ppw, st, true);
-  else launch_xs<bf16_t, 8>(p, slabs, S, ppw, st, true);
+  else if (M <= 128) launch_xs<bf16_t, 8>(p, slabs, S, ppw, st, true);
+  else launch_xs<bf16_t, 16>(p, slabs, S, ppw, st, true);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }
@@ -1029,9 +1049,9 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
                                           void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K, int64_t lda,
                                           int64_t ldb, int dtype, void* stream) {
   const int64_t N = 2 * I;
-  if (M <= 0 || M > 128 || K % 128 != 0 || I % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0) return 1;
+  if (M <= 0 || M > 256 || K % 128 != 0 || I % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0) return 1;
   if ((((uintptr_t)a | (uintptr_t)b_nk) & 15) || ((uintptr_t)q_out & 3)) return 1;
-  if (xs_waves(N) != 8) return 1;
+  if (xs_waves(N) != 8 || M > mi_fp8_gemm_partial_max_rows(N)) return 1;
   int S, ppw;
   xs_plan(N, K, &S, &ppw);
   if (S != 1) return 1;
@@ -1047,9 +1067,11 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
   if (dtype == MI_BF16) {
-    if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else LAUNCH_EPI(bf16_t, 8);
+    if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else if (M <= 128) LAUNCH_EPI(bf16_t, 8);
+    else fp8_gemm_xd_kernel<bf16_t, 16, 1, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, nullptr, 1, 2 * ppw, 0, epi);
   } else {
-    if (M <= 16) LAUNCH_EPI(f16_t, 1); else if (M <= 32) LAUNCH_EPI(f16_t, 2); else if (M <= 64) LAUNCH_EPI(f16_t, 4); else LAUNCH_EPI(f16_t, 8);
+    if (M <= 16) LAUNCH_EPI(f16_t, 1); else if (M <= 32) LAUNCH_EPI(f16_t, 2); else if (M <= 64) LAUNCH_EPI(f16_t, 4); else if (M <= 128) LAUNCH_EPI(f16_t, 8);
+    else fp8_gemm_xd_kernel<f16_t, 16, 1, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, nullptr, 1, 2 * ppw, 0, epi);
   }
 #undef LAUNCH_EPI
   MI_CHECK_LAUNCH();

@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __r
 }
 
 // ============================================================================ public entry points
-// Batches beyond 128 rows (graph batch sizes up to 512, C5's batch 256) run the same fused pair once per 128-row
-// chunk, through the same slabs: every output row is produced exactly as in a <= 128-row call on its chunk.
+// Batches beyond one pass of the GEMM (256 rows with the 8-wave kernel, else 128; graph batch sizes up to 512) run
+// the same fused pair once per chunk of rows, through the same slabs: every output row is produced exactly as in a <= 128-row call on its chunk.
 #define FUSED_MAX_M 512
-#define FUSED_CHUNK 128
+MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N);   // fp8_gemm.hip: 256 (8-wave deep-ring kernel) or 128
 extern "C" int64_t mi_fp8_gemm_fused_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M > FUSED_CHUNK && M <= FUSED_MAX_M) M = FUSED_CHUNK;
+  if (N > 0 && M > mi_fp8_gemm_partial_max_rows(N) && M <= FUSED_MAX_M) M = mi_fp8_gemm_partial_max_rows(N);
   const int S = mi_fp8_gemm_plan_splits(M, N, K);
   return S > 0 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
 }
@@ -266,6 +266,7 @@ extern "C" int mi_fp8_gemm_add_rmsnorm_fp8(const void* a, const void* b_nk, cons
                                            const float* q_scale, int64_t M, int64_t N, int64_t K, int64_t lda,
                                            int64_t ldb, float eps, int dtype, void* workspace,
                                            int64_t workspace_bytes, void* stream) {
+  const int64_t FUSED_CHUNK = N > 0 ? mi_fp8_gemm_partial_max_rows(N) : 128;
   if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
     MI_CHECK_ARG(a && b_nk && (out || q_out));
     const int64_t es = 2;   // bf16 / fp16
@@ -294,6 +295,7 @@ extern "C" int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const f
                                         int64_t lda, int64_t ldb, int64_t ldq, int64_t cache_stride_k,
                                         int64_t cache_stride_v, int dtype, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
+  const int64_t FUSED_CHUNK = mi_fp8_gemm_partial_max_rows((num_q_heads + 2 * num_kv_heads) * head_dim);
   if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
     MI_CHECK_ARG(a && b_nk && positions && q_out && loc);
     for (int64_t m0 = 0; m0 < M; m0 += FUSED_CHUNK) {
@@ -323,6 +325,7 @@ extern "C" int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const f
                                         int64_t lda, int64_t ldb, int dtype, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
   MI_CHECK_ARG(I > 0 && q_out && q_scale);
+  const int64_t FUSED_CHUNK = mi_fp8_gemm_partial_max_rows(2 * I);
   if (M > FUSED_CHUNK && M <= FUSED_MAX_M) {
     MI_CHECK_ARG(a && b_nk);
     for (int64_t m0 = 0; m0 < M; m0 += FUSED_CHUNK) {

@@ -341,7 +341,8 @@ int mi_silu_and_mul(const void* x, void* out, int64_t M, int64_t I, int64_t ldx,
 
 /* ------------------------- decode-shaped FP8 linears fused with their consumer
  *
- * M <= 512 (run per 128-row chunk through the same workspace; every row comes out as from a call on its chunk),
+ * M <= 512 (beyond one GEMM pass -- 256 rows, 128 when N < 1024 -- run per chunk through the same workspace; every
+ * row comes out exactly as from a <= 128-row call),
  * K % 128 == 0, per-tensor scales.  The GEMM leaves raw fp32 split-K partials in `workspace`
  * (mi_fp8_gemm_fused_workspace_bytes(M,N,K) bytes, 16-byte aligned) and ONE consumer kernel sums them,
  * applies the GEMM epilogue x = round_T(acc * sa * sb) and the next op(s) of the decoder layer.  Every
