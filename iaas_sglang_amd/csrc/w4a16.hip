@@ -343,8 +343,10 @@ static void w4_plan(int64_t N, int64_t K, int* S, int* ppw) {
   *S = (int)cdiv64(nph, per);
 }
 
+#define W4_CHUNK_MAX_M 512   // batches of 129..512 rows: the decode kernel once per 128-row chunk (above: dequant + dense GEMM)
 extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M > 128 || M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  if (M > W4_CHUNK_MAX_M || M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  if (M > 128) M = 128;
   int S, ppw;
   w4_plan(N, K, &S, &ppw);
   return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
@@ -362,7 +364,20 @@ static void launch_w4_xs(const W4Params& p, float* slab, int S, int ppw, hipStre
 // returns false when the shape / workspace does not allow this path
 template <typename T>
 static bool try_w4_xs(const W4Params& p, void* workspace, int64_t workspace_bytes, hipStream_t st) {
-  if (p.M > 128 || p.perm || p.group % 128 != 0) return false;
+  if (p.M > W4_CHUNK_MAX_M || p.perm || p.group % 128 != 0) return false;
+  if (p.M > 128) {
+    // decode batches beyond 128 rows (graph batch sizes up to 512): the fallback kernel below re-reads and re-dequantises
+    // the weights per 64-row block (measured M=256: 70-350 us per Llama-2-7B GEMM against 21-46 us at M=128);
+    // the x-stationary kernel once per 128-row chunk streams them twice at full rate instead
+    for (int64_t m0 = 0; m0 < p.M; m0 += 128) {
+      W4Params q = p;
+      q.M = p.M - m0 < 128 ? p.M - m0 : 128;
+      q.x = (const char*)p.x + m0 * p.ldx * 2;
+      q.out = (char*)p.out + m0 * p.ldo * 2;
+      if (!try_w4_xs<T>(q, workspace, workspace_bytes, st)) return false;   // only possible for the first chunk
+    }
+    return true;
+  }
   int S, ppw;
   w4_plan(p.N, p.K, &S, &ppw);
   const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
@@ -410,6 +425,44 @@ extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* z
     if (try_w4_xs<bf16_t>(p, workspace, workspace_bytes, st)) { MI_CHECK_LAUNCH(); return MI_OK; }
     if (perm) launch_w4<bf16_t, true>(p, st); else launch_w4<bf16_t, false>(p, st);
   }
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ------------------------------------------------------- native layout -> dense [N, K] (prefill route)
+// Large batches (prefill) are MFMA-bound on a DENSE GEMM, where a fused dequant only adds VALU work per tile: there
+// the reference's own algorithm is the right one -- materialise W once, then one library GEMM (awq.py:199-203).
+// One thread per native dword = 8 consecutive k of one output column, written as one 16-byte store into W^T [N, K]
+// (K contiguous: the NT operand F.linear wants).  Same Deq<T> as the fused kernels: bit-identical weights.
+template <typename T>
+__global__ __launch_bounds__(256) void w4_dequant_native_kernel(const uint32_t* __restrict__ qw,
+                                                                const uint32_t* __restrict__ zs, T* __restrict__ w_nk,
+                                                                int64_t N, int64_t K, int64_t group) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (N / 16) * (K / 128) * 256) return;
+  const int s = gid & 3, lane = (gid >> 2) & 63;
+  const int64_t blk = gid >> 8;
+  const int64_t kb = blk % (K / 128), nt = blk / (K / 128);
+  const int64_t n = nt * 16 + (lane & 15);
+  const int64_t k0 = kb * 128 + 32 * s + 8 * (lane >> 4);
+  const auto v = Deq<T>::run(qw[gid], zs[(k0 / group) * N + n]);
+  *(uint4*)(w_nk + n * K + k0) = __builtin_bit_cast(uint4, v);
+}
+
+extern "C" int mi_w4_dequantize_native(const void* qw_native, const void* zs_native, void* w_nk, int64_t N, int64_t K,
+                                       int64_t group_size, int dtype, void* stream) {
+  MI_CHECK_ARG(qw_native && zs_native && w_nk && N > 0 && K > 0);
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
+  if (group_size <= 0) group_size = K;
+  if (N % 16 != 0 || K % 128 != 0 || group_size % 8 != 0)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_w4_dequantize_native: need N%%16==0, K%%128==0, group%%8==0");
+  MI_CHECK_ARG((((uintptr_t)qw_native | (uintptr_t)w_nk) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((N / 16) * (K / 128));
+  if (dtype == MI_FP16)
+    w4_dequant_native_kernel<f16_t><<<blocks, 256, 0, st>>>((const uint32_t*)qw_native, (const uint32_t*)zs_native, (f16_t*)w_nk, N, K, group_size);
+  else
+    w4_dequant_native_kernel<bf16_t><<<blocks, 256, 0, st>>>((const uint32_t*)qw_native, (const uint32_t*)zs_native, (bf16_t*)w_nk, N, K, group_size);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -336,15 +336,44 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, grou
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1
     M, K = x.shape
-    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    if M > W4_DENSE_MIN_ROWS and K % 128 == 0 and N % 16 == 0:
+        # prefill: MFMA-bound on a dense GEMM -- dequantise once (our kernel, native layout) and hand the product to
+        # the library GEMM, which is the reference's own algorithm (awq.py:199-203: awq_dequantize + torch.matmul)
+        w_nk = w4_dequantize_native(qw, zs, N, K, group_size, x.dtype)
+        xp = x if perm is None else x.index_select(1, perm.to(torch.int64))
+        y = torch.nn.functional.linear(xp, w_nk, bias)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     ws_bytes = lib.mi_w4a16_gemm_workspace_bytes(M, N, K) if perm is None else 0
     ws = _gemm_workspace(ws_bytes, x.device) if ws_bytes else None
     check(lib.mi_w4a16_gemm(_ptr(x), _ptr(qw), _ptr(zs), _ptr(perm), _ptr(bias), _ptr(out), M, N, K,
                             int(group_size), x.stride(0), out.stride(0), _dt(x), _ptr(ws),
                             ws_bytes if ws is not None else 0, _stream()), "mi_w4a16_gemm")
     return out
+
+
+W4_DENSE_MIN_ROWS = 512      # above: dequantise + dense GEMM; up to it: the fused dequant kernels (128-row chunks)
+_w4_dense_scratch: dict = {}
+
+
+def w4_dequantize_native(qw: torch.Tensor, zs: torch.Tensor, N: int, K: int, group_size: int,
+                         dtype: torch.dtype) -> torch.Tensor:
+    """W^T [N, K] in `dtype` from the load-time native layout (mi_w4_dequantize_native), into a scratch buffer that is
+    reused by the next call on the same device/dtype (the dense weight lives for one GEMM only)."""
+    key = (qw.device, dtype)
+    buf = _w4_dense_scratch.get(key)
+    if buf is None or buf.numel() < N * K:
+        buf = torch.empty(N * K, dtype=dtype, device=qw.device)
+        _w4_dense_scratch[key] = buf
+    w = buf[: N * K].view(N, K)
+    check(lib.mi_w4_dequantize_native(_ptr(qw), _ptr(zs), _ptr(w), N, K, int(group_size), _DT[dtype], _stream()),
+          "mi_w4_dequantize_native")
+    return w
 
 
 def w4_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, group_size: int,

@@ -261,6 +261,14 @@ int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native,
 /* bytes of split-K scratch mi_w4a16_gemm can use (0: none needed); less is correct but slower */
 int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+/* W^T [N,K] (K contiguous) = dequant(native-layout weights) in `dtype`: the prefill route -- for batches beyond ~512
+ * rows the reference's own algorithm (materialise W once, then one dense library GEMM, awq.py:199-203) beats a fused
+ * dequant, which would repeat the VALU work per output tile.  Same bits as the fused kernels' fragments.  With GPTQ
+ * act-order the rows are the PERMUTED ones: multiply by x[:, perm].
+ * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221 (on our load-time layout). */
+int mi_w4_dequantize_native(const void* qw_native, const void* zs_native, void* w_nk, int64_t N, int64_t K,
+                            int64_t group_size, int dtype, void* stream);
+
 /* W[K,N] = dequant(checkpoint-layout qweight) in `dtype` (unfused form, for tests and tools).
  * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221. */
 int mi_w4_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* scales,

@@ -125,7 +125,9 @@ def _rand_awq(K, N, g, dtype, gen):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,g", [(1, 128, 256, 128), (64, 4096, 4096, 128), (19, 256, 1024, 128),
-                                     (64, 12288, 4096, 128), (33, 64, 11008, 128)])
+                                     (64, 12288, 4096, 128), (33, 64, 11008, 128),
+                                     (200, 4096, 4096, 128), (512, 1024, 1024, 128),      # 128-row chunks of the decode kernel
+                                     (513, 1024, 2048, 128), (2048, 4096, 1024, 128)])    # dequantise + dense GEMM
 def test_awq_fused_gemm_vs_oracle(dtype, M, N, K, g):
     from iaas_sglang_amd._lib import MI_W4_AWQ
     o_ = ops()
@@ -142,6 +144,10 @@ def test_awq_fused_gemm_vs_oracle(dtype, M, N, K, g):
     # the dense dequant op agrees bit-for-bit with the oracle
     Wd = o_.w4_dequantize(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), g, MI_W4_AWQ)
     assert torch.equal(Wd.cpu(), W.to(dtype))
+    # ... and so does the dense W^T the prefill route builds from the load-time layout
+    if K % 128 == 0 and N % 16 == 0:
+        Wn = o_.w4_dequantize_native(qw, zs, N, K, g, dtype)
+        assert torch.equal(Wn.cpu().t(), W.to(dtype))
 
 
 @pytest.mark.parametrize("act_order", [False, True])
@@ -168,6 +174,10 @@ def test_gptq_fused_gemm_vs_oracle(act_order):
     torch.testing.assert_close(y.cpu().float(), ref, rtol=2 ** -9, atol=3e-2)
     Wd = o_.w4_dequantize(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), g, MI_W4_GPTQ, g_idx.to(DEV))
     assert torch.equal(Wd.cpu(), W.to(torch.float16))
+    # prefill route (dequantise the native layout + dense GEMM; act-order: permuted rows against x[:, perm])
+    xl = torch.randn(600, K, generator=gen).to(torch.float16)
+    yl = o_.w4a16_gemm(xl.to(DEV), qw, zs, N, g, perm)
+    torch.testing.assert_close(yl.cpu().float(), xl.float() @ W.float(), rtol=2 ** -9, atol=3e-2)
 
 
 def test_input_to_float8_weight_mode_golden(golden_quant):
