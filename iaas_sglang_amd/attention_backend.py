@@ -99,28 +99,42 @@ class MiAttnBackend(AttentionBackend):
         self._ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ helpers
-    def _choose_splits(self, bs: int, seq_lens_sum: int) -> int:
+    def _heads_per_wg(self) -> int:
+        return 8 if self.num_kv_head % 8 == 0 else 4 if self.num_kv_head % 4 == 0 else 2 if self.num_kv_head % 2 == 0 else 1
+
+    def _split_cap(self, bs: int) -> int:
+        """Most splits a request may get.  --triton-attention-num-kv-splits (8) is the cap at serving batch sizes; a
+        few long requests need more to reach every CU (B=1, S=32768: 8 splits 490 us, 64 splits 81-107 us), so small
+        batches may go up to 64 -- never beyond what the workspace of a graph (max_bs x max_kv_splits) can hold."""
+        per_req = self.num_kv_head // self._heads_per_wg()
+        return max(self.max_kv_splits, min(64, 512 // max(bs * per_req, 1)))
+
+    def _choose_splits(self, bs: int, seq_lens_sum: int, cap: Optional[int] = None) -> int:
         """Split-KV count (replaces get_num_kv_splits_triton, triton_backend.py:875-924).  The decode
         kernel runs ONE 8-wave workgroup (8 kv heads of one (request, split)) per CU at a time, every
-        workgroup doing the same work, so the time is  rounds x (keys per split + a fixed ramp):
+        workgroup doing the same work, so the time is  rounds x (keys per split + a fixed ramp) + the merge:
         pick the split count that minimises it -- i.e. a workgroup count that fills whole rounds of the
         chip (measured at B=128, S=2048: 2 splits = 256 workgroups 183 us, 3 splits 223 us, 4 splits
-        194 us).  Never below ~256 keys per split.  Any value gives the same math up to fp32 reassociation."""
-        heads_per_wg = 8 if self.num_kv_head % 8 == 0 else 4 if self.num_kv_head % 4 == 0 else \
-            2 if self.num_kv_head % 2 == 0 else 1
+        194 us).  Never below ~256 keys per split (512 beyond the serving cap: the merge walks the splits
+        serially, ~0.75 us each).  Any value gives the same math up to fp32 reassociation."""
+        heads_per_wg = self._heads_per_wg()
         wgs = bs * (self.num_kv_head // heads_per_wg)
         slots = self.cu_count * max(1, 8 // heads_per_wg)        # co-resident workgroups on the chip
         avg = max(seq_lens_sum // max(bs, 1), 1)
-        ramp = 96                                               # launch + first-tile latency, in keys
+        ramp, merge = 96, 4.7                                   # launch + first-tile latency / merge step, in keys
+        cap = self._split_cap(bs) if cap is None else cap
         best, best_cost = 1, None
-        for s in range(1, max(1, min(self.max_kv_splits, avg // 256)) + 1):
+        for s in range(1, max(1, cap) + 1):
+            if s > 1 and (avg // s < 256 or (s > self.max_kv_splits and avg // s < 512)):
+                break
             rounds = -(-wgs * s // slots)
-            cost = rounds * (-(-avg // s) + ramp)
+            cost = rounds * (-(-avg // s) + ramp) + merge * s
             if best_cost is None or cost < best_cost:
                 best, best_cost = s, cost
         return best
 
-    def _plan_on_host(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None, force_list: bool = False):
+    def _plan_on_host(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None, force_list: bool = False,
+                      cap: Optional[int] = None):
         """(num_kv_splits, split_chunk, host work list or None).  Uniform batches: _choose_splits, no chunk, no list
         (with `force_list`: the full (request, split) grid, split index outermost).  RAGGED batches (longest request
         > 1.5x the mean): fixed-size splits of `chunk` keys and a launch list of the non-empty (request, split) pairs
@@ -128,7 +142,8 @@ class MiAttnBackend(AttentionBackend):
         with the short pieces (longest-processing-time-first packing).  Measured at B=128, S_i ~ U[1,4096] (257 k
         keys): per-request S/2 splits 280 us, S/8 245-270 us, fixed chunks in grid order 260-300 us, this list: see
         DESIGN.md section 3.1; the uniform batch of the same size takes 183 us."""
-        splits = self._choose_splits(bs, seq_lens_sum)
+        cap = self._split_cap(bs) if cap is None else cap
+        splits = self._choose_splits(bs, seq_lens_sum, cap)
         ragged = False
         if seq_lens_cpu is not None and bs > 1:
             lens = torch.as_tensor(seq_lens_cpu)[:bs].to(torch.int64)
@@ -139,7 +154,7 @@ class MiAttnBackend(AttentionBackend):
                 return splits, 0, None
             work = torch.stack([torch.arange(bs).repeat(splits), torch.arange(splits).repeat_interleave(bs)], dim=1)
             return splits, 0, work.to(torch.int32)
-        chunk = max(getattr(self, "min_split_chunk", 512), -(-mx // self.max_kv_splits))
+        chunk = max(getattr(self, "min_split_chunk", 512), -(-mx // cap))
         chunk = (chunk + 15) // 16 * 16
         nsplit = -(-mx // chunk)
         full, rem = lens // chunk, lens % chunk
@@ -259,14 +274,20 @@ class MiAttnBackend(AttentionBackend):
     def _write_graph_plan(self, bs: int, seq_lens_sum: int, seq_lens_cpu, gplan=None):
         """Plan this replay on the host and ship {num_work, num_splits, split_chunk | work list} to the device buffer
         the captured kernels read (one small async copy from rotating pinned buffers, no host sync)."""
-        splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu, force_list=True)
-        assert splits <= self.max_kv_splits and work.shape[0] <= bs * self.max_kv_splits
+        cap = self._graph_split_cap(bs)
+        splits, chunk, work = self._plan_on_host(bs, seq_lens_sum, seq_lens_cpu, force_list=True, cap=cap)
+        assert splits <= cap and work.shape[0] <= bs * cap
         (gplan or self._gplan).write(splits, chunk, work)
 
+    def _graph_split_cap(self, bs: int) -> int:
+        """_split_cap within what init_cuda_graph_state allocated (workspace and work list hold max_bs x max_kv_splits)."""
+        return max(self.max_kv_splits, min(self._split_cap(bs), self._gplan.cap // max(bs, 1)))
+
     def _graph_metadata(self, bs: int, kv_indptr, kv_indices=None, gplan=None) -> ForwardMetadata:
-        work, plan = (gplan or self._gplan).views(bs * self.max_kv_splits)
+        cap = self._graph_split_cap(bs)
+        work, plan = (gplan or self._gplan).views(bs * cap)
         return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices if kv_indices is None else kv_indices, None, None,
-                               self.max_kv_splits, self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
+                               cap, self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
 
     def _graph_window(self, bs, req_pool_indices, seq_lens, seq_lens_sum, seq_lens_cpu) -> Optional[ForwardMetadata]:
         """Capture and replay of the sliding-window set (update_sliding_window_buffer_cuda_graph,

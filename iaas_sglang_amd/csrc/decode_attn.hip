@@ -457,11 +457,18 @@ template <typename T, int D, int G, bool KV8>
 static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st) {
   static const int wenv = env_int("MI_DECODE_W", 0);
   const int h = p.num_kv_heads;
-  if (wenv == 4 && h % 4 == 0) launch_decode<T, D, G, 4, KV8>(p, batch, st);
-  else if (wenv == 2 && h % 2 == 0) launch_decode<T, D, G, 2, KV8>(p, batch, st);
-  else if (h % 8 == 0 && G < 16) launch_decode<T, D, G, 8, KV8>(p, batch, st);   // G=16: 128 accumulator VGPRs, keep the 512-VGPR budget of <= 4 waves
-  else if (h % 4 == 0) launch_decode<T, D, G, 4, KV8>(p, batch, st);
-  else if (h % 2 == 0) launch_decode<T, D, G, 2, KV8>(p, batch, st);
+  // kv heads (= waves) per workgroup: 8 fills a CU with one workgroup, but a small batch x few splits (long-context
+  // decode of a few requests) then leaves most CUs idle -- halve W until the launch has ~one workgroup per CU
+  // (measured B=8, S=8192, 16 splits: W=8 90 us, W=4 65 us; B=1, S=32768, 64 splits: 107 / 86 / 81 us for W=8/4/2)
+  int w = h % 8 == 0 && G < 16 ? 8 : h % 4 == 0 ? 4 : h % 2 == 0 ? 2 : 1;   // G=16: 128 accumulator VGPRs, <= 4 waves
+  const int64_t items = p.work ? p.num_work : batch * p.num_splits;
+  while (w > 2 && items * (h / w) < 256) w >>= 1;
+  if (wenv == 8 && h % 8 == 0 && G < 16) w = 8;
+  else if (wenv == 4 && h % 4 == 0) w = 4;
+  else if (wenv == 2 && h % 2 == 0) w = 2;
+  if (w == 8) launch_decode<T, D, G, 8, KV8>(p, batch, st);
+  else if (w == 4) launch_decode<T, D, G, 4, KV8>(p, batch, st);
+  else if (w == 2) launch_decode<T, D, G, 2, KV8>(p, batch, st);
   else launch_decode<T, D, G, 1, KV8>(p, batch, st);
 }
 

@@ -640,3 +640,49 @@ def test_backend_sliding_window_decode_matches_oracle(graph):
         torch.testing.assert_close(o_full.view(bs, Hq, D).cpu().float(), want_full, atol=4e-3, rtol=2 ** -7)
         torch.testing.assert_close(o_win.view(bs, Hq, D).cpu().float(), want_win, atol=4e-3, rtol=2 ** -7)
         assert not torch.allclose(want_win[2], want_full[2], atol=1e-2) or lens[2] <= W + 1   # the window really matters
+
+
+@pytest.mark.parametrize("lens", [[12000], [9000, 300], [4096, 4096, 4096, 4096]])
+@pytest.mark.parametrize("graph", [False, True])
+def test_backend_small_batch_long_context_splits_beyond_the_serving_cap(lens, graph):
+    """A few long requests: more than --triton-attention-num-kv-splits splits (and fewer kv heads per workgroup) so
+    that the launch reaches every CU; eager plan and the device-side plan of a captured launch; vs the oracle."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype = H.LLAMA3_8B, torch.bfloat16
+    Hq, Hkv, D = 32, 8, 128
+    bs, tot = len(lens), sum(lens)
+    runner = H.make_runner(shape, max_reqs=4, ctx=12288, pool_tokens=tot + 8, dtype=dtype, device=DEV, fill_kv=True)
+    runner.token_to_kv_pool = H.make_kv_pool(tot + 8, 1, Hkv, D, dtype, DEV, fill_random=True)
+    backend = MiAttnBackend(runner)
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    fb = H.make_decode_batch(runner, backend, bs, 0, DEV, seed=5, ragged=torch.tensor(lens))
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(bs, Hq * D, generator=g).to(dtype).to(DEV)
+    if graph:
+        backend.init_cuda_graph_state(bs, bs)
+        rpi, seq_lens = fb.req_pool_indices.clone(), torch.ones(bs, dtype=torch.int64, device=DEV)
+        fbg = H.make_decode_batch(runner, backend, bs, 0, DEV, seed=5, ragged=torch.tensor(lens))
+        fbg.req_pool_indices, fbg.seq_lens = rpi, seq_lens
+        backend.init_forward_metadata_capture_cuda_graph(bs, bs, rpi, seq_lens, None, H.ForwardMode.DECODE, None)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            og = backend.forward(q, None, None, layer, fbg, save_kv_cache=False)
+        seq_lens.copy_(fb.seq_lens)
+        backend.init_forward_metadata_replay_cuda_graph(bs, rpi, seq_lens, tot, None, H.ForwardMode.DECODE, None,
+                                                        fb.seq_lens_cpu)
+        cg.replay()
+        torch.cuda.synchronize()
+        o = og.clone()
+        assert int(backend.cuda_graph_plan_buf[1]) <= backend._graph_split_cap(bs)
+    else:
+        backend.init_forward_metadata(fb)
+        md = backend.forward_metadata
+        assert md.num_kv_splits >= backend.max_kv_splits and (bs > 2 or md.num_kv_splits > backend.max_kv_splits)
+        o = backend.forward(q, None, None, layer, fb, save_kv_cache=False)
+    pool = runner.token_to_kv_pool
+    want = oa.decode_fp32(q.view(bs, Hq, D).cpu(), pool.k_buffer[0].cpu(), pool.v_buffer[0].cpu(),
+                          runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(), torch.tensor(lens),
+                          scaling=D ** -0.5)
+    torch.testing.assert_close(o.view(bs, Hq, D).cpu().float(), want, atol=4e-3, rtol=2 ** -7)

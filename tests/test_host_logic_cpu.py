@@ -77,7 +77,11 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     assert be._choose_splits(64, 64 * 2048) == 4            # 64 x 4 = 256 workgroups
     assert be._choose_splits(96, 96 * 2048) in (2, 5)       # 192 or 480 workgroups: never 3 (288 = 1.1 rounds)
     assert be._choose_splits(1, 100) == 1                    # never split below ~256 keys
-    assert be._choose_splits(1, 100000) == 8                 # capped by --triton-attention-num-kv-splits
+    assert be._choose_splits(1, 100000) == 64                # a few long requests: beyond the serving cap, to reach every CU
+    assert be._choose_splits(1, 100000, cap=8) == 8          # ... unless the caller's buffers cap it
+    assert be._choose_splits(8, 8 * 8192) == 16              # >= 512 keys per split beyond --triton-attention-num-kv-splits
+    assert be._choose_splits(32, 32 * 4096) == 8
+    assert be._split_cap(1) == 64 and be._split_cap(32) == 16 and be._split_cap(128) == 8
     assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
     # ragged batches are split by their longest request; uniform ones by the whole-rounds model
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
