@@ -39,6 +39,8 @@ SIGNATURES = {
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
+    "mi_extend_attn_splitkv": (_int, [_p] * 6 + [_int, _f, _f] + [_p] * 5 + [_int] + [_i64] * 11 + [_f, _f, _int, _i64, _p, _i64, _i64,
+                                      _int, _p]),
     "mi_extend_attn_masked": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _i64,
                                      _i64, _i64, _i64, _i64, _i64, _f, _f, _i64, _int, _p]),
     "mi_merge_state": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),

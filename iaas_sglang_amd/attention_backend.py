@@ -194,6 +194,22 @@ class MiAttnBackend(AttentionBackend):
         return ForwardMetadata(indptr, indices, None, None, splits, self._workspace(bs, splits), split_chunk=chunk,
                                work=work)
 
+    def _choose_extend_splits(self, ext_lens, prefix_lens) -> int:
+        """Split-KV count of an extend / verify launch.  The kernel puts one workgroup on every (request, 64 query rows
+        = 64 / heads-per-group tokens, kv head): a verify batch of 4 x 8 draft tokens over 8 k cached keys is 32
+        workgroups, each walking its 8 k keys alone (453 us measured; the bytes are worth 27 us).  The chip holds ~4 of
+        these 4-wave workgroups per CU, so aim at ~1024 of them: split the key range (>= 512 keys per split, up to 32
+        splits) and merge as decode does.  Measured: 4 x 8 over 8192 keys 453 -> 68 us (16 splits), 16 x 8 over 4096
+        248 -> 75 us (8), one 64-token chunk over 32000 keys 1685 -> 149 us (16)."""
+        group = max(self.num_head // max(self.num_kv_head, 1), 1)
+        hg = 4 if group % 4 == 0 else 2 if group % 2 == 0 else 1
+        bq = 64 // hg
+        wgs = sum(-(-int(e) // bq) for e in ext_lens) * self.num_kv_head * (group // hg)
+        keys = max((int(p_) + int(e) for p_, e in zip(prefix_lens, ext_lens)), default=0)
+        if wgs <= 0 or wgs >= 768:
+            return 1
+        return max(1, min(32, 1024 // wgs, keys // 512))
+
     def _workspace(self, bs: int, splits: int) -> Optional[torch.Tensor]:
         n = ops.decode_workspace_numel(bs, self.num_head, self.v_head_dim, splits)
         if n == 0:
@@ -223,7 +239,10 @@ class MiAttnBackend(AttentionBackend):
             seq_mask_len = nd * (forward_batch.seq_lens.to(torch.int64) + nd)
             mask_indptr = self.mask_indptr
             mask_indptr[1: bs + 1] = torch.cumsum(seq_mask_len[:bs], dim=0)     # plumbing, as the reference does it
-            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, nd, 1, None,
+            lens_cpu = getattr(forward_batch, "seq_lens_cpu", None)
+            splits = self._choose_extend_splits([nd] * bs, lens_cpu.tolist()) if lens_cpu is not None else 1
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, nd, splits,
+                                                    self._workspace(bs * nd, splits),
                                                     custom_mask=spec_info.custom_mask, mask_indptr=mask_indptr[: bs + 1])
             return
         if mode.is_decode_or_idle():
@@ -251,7 +270,10 @@ class MiAttnBackend(AttentionBackend):
             ops.kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens,
                            kv_indptr, kv_indices)
             qo_indptr = ops.kv_indptr(forward_batch.extend_seq_lens, self.qo_indptr)
-            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, 1, None)
+            splits = self._choose_extend_splits(ext_cpu, prefix_cpu) if ext_cpu is not None and prefix_cpu is not None else 1
+            tokens = int(sum(ext_cpu)) if ext_cpu is not None else 0
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, splits,
+                                                    self._workspace(tokens, splits))
 
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
         """Preallocate everything replay touches (triton_backend.py:338-388).  Beyond the reference's buffers: the
@@ -416,34 +438,35 @@ class MiAttnBackend(AttentionBackend):
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
         window = getattr(layer, "sliding_window_size", -1)
         window = -1 if window is None else int(window)
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        k3 = k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim)
+        v3 = v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim)
+        o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        cap = getattr(layer, "logit_cap", 0.0) or 0.0
+        fp8_pool = k_buf.element_size() == 1
+        if md.num_kv_splits > 1 or (fp8_pool and md.custom_mask is not None):
+            # short extends over long prefixes (speculative verify, chunk tails): split-KV form of the same kernel;
+            # it is also the general entry point (fp8 pool + tree mask)
+            ks, vs = self._kv_scales(layer) if fp8_pool else (1.0, 1.0)
+            ops.extend_attention_splitkv(q3, k3, v3, o3, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices,
+                                         md.max_extend_len, layer.scaling, md.num_kv_splits, md.workspace, cap,
+                                         causal, window if window > 0 else -1, ks, vs, md.custom_mask, md.mask_indptr,
+                                         True)
+            return o
         if md.custom_mask is not None:
-            if k_buf.element_size() == 1:
-                raise NotImplementedError("MiAttnBackend: TARGET_VERIFY over an fp8 KV pool is not wired")
-            ops.extend_attention_masked(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
-                                        k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
-                                        v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
-                                        o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
-                                        md.kv_indptr, md.kv_indices, md.custom_mask, md.mask_indptr, md.max_extend_len,
-                                        layer.scaling, getattr(layer, "logit_cap", 0.0) or 0.0, True,
+            ops.extend_attention_masked(q3, k3, v3, o3, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices,
+                                        md.custom_mask, md.mask_indptr, md.max_extend_len, layer.scaling, cap, True,
                                         window if window > 0 else -1)
             return o
-        if k_buf.element_size() == 1:
+        if fp8_pool:
             # fp8 pool: the cached prefix is read (and converted) from the pool; the new tokens are attended from
             # the T-typed k/v arguments, exactly as in the bf16 case (they were just written to the pool in fp8)
             ks, vs = self._kv_scales(layer)
-            ops.extend_attention_fp8kv(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
-                                       k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
-                                       v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
-                                       o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, ks, vs,
-                                       md.qo_indptr, md.kv_indptr, md.kv_indices, md.max_extend_len, layer.scaling,
-                                       getattr(layer, "logit_cap", 0.0) or 0.0, causal, window if window > 0 else -1)
+            ops.extend_attention_fp8kv(q3, k3, v3, o3, k_buf, v_buf, ks, vs, md.qo_indptr, md.kv_indptr, md.kv_indices,
+                                       md.max_extend_len, layer.scaling, cap, causal, window if window > 0 else -1)
             return o
-        ops.extend_attention(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
-                             k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
-                             v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim),
-                             o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
-                             md.kv_indptr, md.kv_indices, md.max_extend_len, layer.scaling,
-                             getattr(layer, "logit_cap", 0.0) or 0.0, causal, window if window > 0 else -1)
+        ops.extend_attention(q3, k3, v3, o3, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices, md.max_extend_len,
+                             layer.scaling, cap, causal, window if window > 0 else -1)
         return o
 
     def support_triton(self):

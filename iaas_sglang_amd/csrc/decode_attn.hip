@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   const float* ml = ws_ml + bh * nsplit * 2;
   // splits that exist for this request (the same rule as the split kernel): with a work list the others were never
   // launched and their workspace entries are undefined
-  int nvalid;
-  {
+  int nvalid = nsplit;   // no kv_indptr (extend split-KV): every split wrote its (m, l), empty ones l = 0
+  if (kv_indptr) {
     const int64_t bq = bh / num_q_heads;
     const int32_t S = kv_indptr[bq + 1] - kv_indptr[bq];
     const int ne = plan ? plan[1] : nsplit;
@@ -436,6 +436,19 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------- host side
+MI_INTERNAL int mi_attn_merge_splits(const float* ws_o, const float* ws_ml, void* o, int64_t rows, int64_t num_q_heads,
+                                     int64_t num_splits, int64_t stride_o_tok, int64_t head_dim, int dtype, void* stream) {
+  const int64_t n_bh = rows * num_q_heads;
+  const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
+  hipStream_t st = (hipStream_t)stream;
+#define MERGE_X(TT, DD) decode_merge_kernel<TT, DD><<<blocks, 256, 0, st>>>(ws_o, ws_ml, (TT*)o, n_bh, (int)num_q_heads, (int)num_splits, stride_o_tok, nullptr, nullptr, 1.f, nullptr, 0, nullptr)
+  if (dtype == MI_BF16) { if (head_dim == 128) MERGE_X(bf16_t, 128); else MERGE_X(bf16_t, 64); }
+  else { if (head_dim == 128) MERGE_X(f16_t, 128); else MERGE_X(f16_t, 64); }
+#undef MERGE_X
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
 extern "C" int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_heads,
                                                   int64_t v_head_dim, int64_t num_splits) {
   if (num_splits <= 1) return 0;

@@ -18,6 +18,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+// decode_attn.hip: merge [rows][heads][splits] partials (unnormalised O, m, l) into o [rows, heads, D]
+MI_INTERNAL int mi_attn_merge_splits(const float* ws_o, const float* ws_ml, void* o, int64_t rows, int64_t num_q_heads,
+                                     int64_t num_splits, int64_t stride_o_tok, int64_t head_dim, int dtype, void* stream);
+
 struct ExtendParams {
   const void* q;
   const void* k_ext;
@@ -39,6 +43,12 @@ struct ExtendParams {
   const uint8_t* custom_mask;
   const int64_t* mask_indptr;
   int32_t skip_prefix_mask;
+  // split-KV (short extends over long prefixes: speculative verify, chunk tails): grid.z = batch * num_splits, split s
+  // walks key tiles [s * tps, (s+1) * tps) of its block and leaves (unnormalised O, m, l) in the decode kernel's
+  // workspace layout [token][head][split]; the decode merge kernel combines them
+  int32_t num_splits;
+  float* ws_o;
+  float* ws_ml;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -79,7 +89,8 @@ void extend_attn_kernel(const ExtendParams p) {
   const int hgroups = p.group / HG;
   const int hk = blockIdx.y / hgroups;
   const int hg = blockIdx.y % hgroups;
-  const int req = blockIdx.z;
+  const int req = blockIdx.z / p.num_splits;
+  const int split = blockIdx.z % p.num_splits;
 
   const int32_t q_start = p.qo_indptr[req];
   const int32_t ext_len = p.qo_indptr[req + 1] - q_start;
@@ -110,7 +121,10 @@ void extend_attn_kernel(const ExtendParams p) {
   const int32_t n_keys = prefix + (causal ? blk_last : ext_len);
   const int64_t mask_base = masked ? p.mask_indptr[req] : 0;
   const int32_t seq_len = prefix + ext_len;
-  const int32_t n_tiles = (n_keys + KT - 1) / KT;
+  const int32_t n_tiles_all = (n_keys + KT - 1) / KT;
+  const int32_t tps = (n_tiles_all + p.num_splits - 1) / p.num_splits;   // tiles per split
+  const int32_t t_lo = split * tps;
+  const int32_t n_tiles = min(n_tiles_all, t_lo + tps);                  // this split walks tiles [t_lo, n_tiles)
 
   // ---- staging: thread -> (row srow + TPR*pass, 16-byte chunk schunk); registers between global and LDS
   const int srow = tid / (D / 8), schunk = tid % (D / 8);
@@ -171,13 +185,13 @@ void extend_attn_kernel(const ExtendParams p) {
 
 #pragma unroll
   for (int sub = 0; sub < NSUB; ++sub) {
-    STAGE_LOAD(0, sub);
+    STAGE_LOAD(t_lo, sub);
     STAGE_WRITE(0, sub);
   }
   __syncthreads();
 
-  for (int32_t tile = 0; tile < n_tiles; ++tile) {
-    const int st = tile & 1;
+  for (int32_t tile = t_lo; tile < n_tiles; ++tile) {
+    const int st = (tile - t_lo) & 1;
     const bool has_next = tile + 1 < n_tiles;
     const char* ks_lds = smem + st * STAGE;
     const char* vs_lds = ks_lds + KT * ROW;
@@ -305,6 +319,19 @@ void extend_attn_kernel(const ExtendParams p) {
     float l = lsum[rt];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
+    if (p.num_splits > 1) {
+      if (wave_active && tok0 + 16 * rt + c16 < ext_len) {
+        const int64_t slot = ((int64_t)(q_start + tok0 + 16 * rt + c16) * p.num_q_heads + head) * p.num_splits + split;
+        float* wo = p.ws_o + slot * D + 4 * g4;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(f32x4*)(wo + db * 16) = acc[rt][db];
+        if (g4 == 0) {
+          p.ws_ml[slot * 2] = m[rt];
+          p.ws_ml[slot * 2 + 1] = l;
+        }
+      }
+      continue;
+    }
     if (wave_active && tok0 + 16 * rt + c16 < ext_len) {
       const float inv = 1.f / l;
       T* op = (T*)p.o + (int64_t)(q_start + tok0 + 16 * rt + c16) * p.stride_o_tok + (int64_t)head * D + 4 * g4;
@@ -334,11 +361,11 @@ static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_exte
   static const int big = extend_env("MI_EXTEND_BIG", 0);
   if (big && max_extend_len > 16) {       // 128 rows x 64-key tiles, double-buffered
     constexpr int BQ = 128 / HG;
-    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
+    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)(batch * p.num_splits));
     extend_attn_kernel<T, D, HG, 2, 4, KV8><<<grid, 256, 2 * 2 * 64 * ROW, st>>>(p);
   } else {                                // short extends (speculative verify, chunk tails): 64 rows x 32-key tiles
     constexpr int BQ = 64 / HG;
-    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)batch);
+    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)(batch * p.num_splits));
     extend_attn_kernel<T, D, HG, 1, 2, KV8><<<grid, 256, 2 * 2 * 32 * ROW, st>>>(p);
   }
 }
@@ -361,12 +388,14 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
                             int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                             int64_t sliding_window, int dtype, void* stream, bool kv8, float k_scale, float v_scale,
                             const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
-                            int skip_prefix_mask = 1) {
+                            int skip_prefix_mask = 1, void* workspace = nullptr, int64_t total_tokens = 0,
+                            int64_t num_splits = 1) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
   MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
   MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
-  MI_CHECK_ARG(batch <= 65535);
+  MI_CHECK_ARG(num_splits >= 1 && num_splits <= 64 && batch * num_splits <= 65535);
+  MI_CHECK_ARG(num_splits == 1 || (workspace && total_tokens > 0 && ((uintptr_t)workspace & 15) == 0));
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (head_dim != 64 && head_dim != 128)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_extend_attn: head_dim %lld not supported (64, 128)", (long long)head_dim);
@@ -386,6 +415,9 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   p.k_scale = k_scale; p.v_scale = v_scale;
   MI_CHECK_ARG(!custom_mask || mask_indptr);
   p.custom_mask = custom_mask; p.mask_indptr = mask_indptr; p.skip_prefix_mask = skip_prefix_mask;
+  p.num_splits = (int32_t)num_splits;
+  p.ws_o = (float*)workspace;
+  p.ws_ml = p.ws_o ? p.ws_o + total_tokens * num_q_heads * num_splits * head_dim : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (kv8) {
     MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
@@ -400,7 +432,26 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
     else launch_extend_g<f16_t, 64>(p, batch, max_extend_len, st);
   }
   MI_CHECK_LAUNCH();
+  if (num_splits > 1)
+    return mi_attn_merge_splits(p.ws_o, p.ws_ml, o_ext, total_tokens, num_q_heads, num_splits, stride_o_tok, head_dim, dtype,
+                                stream);
   return MI_OK;
+}
+
+extern "C" int mi_extend_attn_splitkv(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                                      const void* k_buf, const void* v_buf, int kv_fp8, float k_scale, float v_scale,
+                                      const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                      const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask,
+                                      int64_t batch, int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                                      int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_kx_tok,
+                                      int64_t stride_vx_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                                      float logit_cap, int causal, int64_t sliding_window, void* workspace,
+                                      int64_t total_tokens, int64_t num_splits, int dtype, void* stream) {
+  return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, max_extend_len,
+                          num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
+                          stride_k_slot, stride_v_slot, sm_scale, logit_cap, custom_mask ? 0 : causal, sliding_window, dtype,
+                          stream, kv_fp8 != 0, kv_fp8 ? k_scale : 1.f, kv_fp8 ? v_scale : 1.f, custom_mask, mask_indptr,
+                          skip_prefix_custom_mask, workspace, total_tokens, num_splits);
 }
 
 extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,

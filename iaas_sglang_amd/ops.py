@@ -230,6 +230,45 @@ def extend_attention_masked(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.T
     return o
 
 
+def extend_attention_splitkv(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
+                             k_buf: torch.Tensor, v_buf: torch.Tensor, qo_indptr: torch.Tensor,
+                             kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, max_extend_len: int,
+                             sm_scale: float, num_splits: int, workspace: Optional[torch.Tensor] = None,
+                             logit_cap: float = 0.0, causal: bool = True, sliding_window: int = -1,
+                             k_scale: float = 1.0, v_scale: float = 1.0, custom_mask: Optional[torch.Tensor] = None,
+                             mask_indptr: Optional[torch.Tensor] = None,
+                             skip_prefix_custom_mask: bool = True) -> torch.Tensor:
+    """The general extend call (bf16/fp16 or fp8 pool, optional tree mask) with the key range of every query block
+    split `num_splits` ways and merged -- for short extends over long prefixes (speculative verify, chunk tails), where
+    the unsplit launch has a handful of workgroups.  workspace: decode_workspace_numel(E, Hq, D, num_splits) floats."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, o, k_ext, v_ext):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    kv8 = k_buf.element_size() == 1
+    for t in (k_buf, v_buf):
+        assert t.stride(2) == 1 and t.stride(1) == D and (kv8 or t.dtype == q.dtype)
+    assert qo_indptr.dtype == torch.int32 and kv_indptr_t.dtype == torch.int32 and kv_indices_t.dtype == torch.int32
+    if custom_mask is not None:
+        assert custom_mask.dtype in (torch.bool, torch.uint8) and custom_mask.is_contiguous()
+        assert mask_indptr is not None and mask_indptr.dtype == torch.int64 and mask_indptr.numel() >= B + 1
+    num_splits = int(num_splits)
+    if num_splits > 1:
+        need = decode_workspace_numel(E, Hq, D, num_splits)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.float32, device=q.device)
+        assert workspace.dtype == torch.float32 and workspace.numel() >= need
+    check(lib.mi_extend_attn_splitkv(
+        _ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o), _ptr(k_buf), _ptr(v_buf), int(kv8), float(k_scale), float(v_scale),
+        _ptr(qo_indptr), _ptr(kv_indptr_t), _ptr(kv_indices_t), _ptr(custom_mask), _ptr(mask_indptr),
+        int(skip_prefix_custom_mask), B, int(max_extend_len), Hq, Hkv, D, q.stride(0), o.stride(0), k_ext.stride(0),
+        v_ext.stride(0), k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap), int(causal),
+        int(sliding_window), _ptr(workspace) if num_splits > 1 else None, E, num_splits, _dt(q), _stream()),
+        "mi_extend_attn_splitkv")
+    return o
+
+
 def merge_state(o_a, lse_a, o_b, lse_b, out=None, out_lse=None) -> Tuple[torch.Tensor, torch.Tensor]:
     n, h, d = o_a.shape
     assert o_a.is_contiguous() and o_b.is_contiguous() and lse_a.is_contiguous() and lse_b.is_contiguous()

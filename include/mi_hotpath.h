@@ -174,6 +174,24 @@ int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const void* v_ext
                          int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                          int64_t sliding_window, int dtype, void* stream);
 
+/* The general extend call -- bf16/fp16 or fp8 (kv_fp8 != 0: k_scale / v_scale as in mi_extend_attn_fp8kv) pool, optional
+ * tree mask (custom_mask nullable; when given it replaces the causal rule as in mi_extend_attn_masked) -- with SPLIT-KV:
+ * the key range of every query block is walked by num_splits (1..64) workgroups and merged, for short extends over
+ * long prefixes (speculative verify, chunk tails), where the unsplit launch has only batch * heads workgroups.
+ * workspace: mi_decode_attn_workspace_bytes(total_tokens, num_q_heads, head_dim, num_splits) bytes (nullable when
+ * num_splits == 1); total_tokens = qo_indptr[batch].  Same math as the unsplit call up to fp32 reassociation.
+ * replaces: extend_attention_fwd, triton_ops/extend_attention.py:306-438 (which has no split form: the reference
+ * runs verify batches with one program per (sequence, head, 64-row block)). */
+int mi_extend_attn_splitkv(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext, const void* k_buf,
+                           const void* v_buf, int kv_fp8, float k_scale, float v_scale, const int32_t* qo_indptr,
+                           const int32_t* kv_indptr, const int32_t* kv_indices, const uint8_t* custom_mask,
+                           const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t batch,
+                           int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                           int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok,
+                           int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                           int64_t sliding_window, void* workspace, int64_t total_tokens, int64_t num_splits, int dtype,
+                           void* stream);
+
 /* mi_extend_attn with a per-request visibility mask on the NEW-token keys instead of the causal rule
  * (speculative-decode tree verification): request i's mask is a row-major byte matrix
  * [ext_len_i, prefix_i + ext_len_i] at custom_mask + mask_indptr[i] (non-zero = visible); prefix keys are all

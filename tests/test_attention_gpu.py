@@ -210,8 +210,8 @@ EXTEND = ["extend_gqa4_d128_bf16_noprefix", "extend_gqa4_d128_bf16_prefix",
           "extend_mha_d64_fp16_prefix", "extend_gqa4_d128_bf16_noncausal"]
 
 
-def _run_extend(c, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal, logit_cap=0.0, window=-1):
-    """The backend's extend sequence through the C ABI: KV write, prefix kv_indices, kernel."""
+def _run_extend(c, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal, logit_cap=0.0, window=-1, splits=1):
+    """The backend's extend sequence through the C ABI: KV write, prefix kv_indices, kernel (splits > 1: split-KV form)."""
     o_ = ops()
     d = lambda t: t.to(DEV)
     kc, vc = d(kc).clone(), d(vc).clone()
@@ -225,8 +225,12 @@ def _run_extend(c, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal,
     idx = torch.empty(max(1, int(pre.sum())), dtype=torch.int32, device=DEV)
     o_.kv_indices(d(r2t), d(rpi), pre_d, kv_indptr, idx)
     out = torch.empty_like(d(q))
-    o_.extend_attention(d(q), d(k_new), d(v_new), out, kc, vc, qo_indptr, kv_indptr, idx, int(ext.max()),
-                        scaling, logit_cap, causal, window)
+    if splits > 1:
+        o_.extend_attention_splitkv(d(q), d(k_new), d(v_new), out, kc, vc, qo_indptr, kv_indptr, idx, int(ext.max()),
+                                    scaling, splits, None, logit_cap, causal, window)
+    else:
+        o_.extend_attention(d(q), d(k_new), d(v_new), out, kc, vc, qo_indptr, kv_indptr, idx, int(ext.max()),
+                            scaling, logit_cap, causal, window)
     torch.cuda.synchronize()
     return out.cpu(), kc.cpu(), vc.cpu()
 
@@ -280,6 +284,10 @@ def test_extend_ragged_vs_oracle(Hq, Hkv, D, dtype):
         ref = oa.extend_fp32(q, kca, vca, r2t, rpi, torch.tensor(lens), pre, ext, scaling=scaling, causal=causal,
                              logit_cap=cap, sliding_window=window)
         torch.testing.assert_close(out.float(), ref, atol=4e-3, rtol=2 ** -6 if dtype == torch.bfloat16 else 2 ** -8)
+        # split-KV form: 3 splits, and 16 (more splits than key tiles for most blocks: empty splits must merge away)
+        for splits in (3, 16):
+            out_s, _, _ = _run_extend(None, q, k_new, v_new, kc, vc, r2t, rpi, pre, ext, scaling, causal, cap, window, splits)
+            torch.testing.assert_close(out_s.float(), ref, atol=4e-3, rtol=2 ** -6 if dtype == torch.bfloat16 else 2 ** -8)
 
 
 def test_extend_reference_test_shape():
@@ -443,6 +451,11 @@ def test_extend_custom_mask_tree_verify_vs_oracle(dtype, B, nd, Hq, Hkv, D, skip
                                 mask_indptr.to(DEV), nd, D ** -0.5, 0.0, skip_prefix)
     torch.cuda.synchronize()
     torch.testing.assert_close(o.cpu().float(), ref, atol=2e-2, rtol=2e-2)
+    o2 = torch.empty_like(o)
+    ops.extend_attention_splitkv(q.to(DEV), k.to(DEV), v.to(DEV), o2, kc.to(DEV), vc.to(DEV), qo, kvp, idx, nd, D ** -0.5, 4,
+                                 None, 0.0, True, -1, 1.0, 1.0, custom_mask.to(DEV), mask_indptr.to(DEV), skip_prefix)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o2.cpu().float(), ref, atol=2e-2, rtol=2e-2)
 
 
 def test_extend_custom_mask_equal_to_causal_reproduces_causal():
@@ -686,3 +699,51 @@ def test_backend_small_batch_long_context_splits_beyond_the_serving_cap(lens, gr
                           runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(), torch.tensor(lens),
                           scaling=D ** -0.5)
     torch.testing.assert_close(o.view(bs, Hq, D).cpu().float(), want, atol=4e-3, rtol=2 ** -7)
+
+
+def test_backend_verify_over_long_prefixes_splits_the_key_range():
+    """TARGET_VERIFY of a few requests with long committed sequences: the backend picks a split-KV launch (the
+    unsplit one has batch x kv-heads workgroups); result = the oracle's masked extend."""
+    from types import SimpleNamespace
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype, nd = H.LLAMA3_8B, torch.bfloat16, 8
+    Hq, Hkv, D = 32, 8, 128
+    lens = [5000, 3000, 4100]
+    bs, tot = len(lens), sum(lens)
+    runner = H.make_runner(shape, max_reqs=4, ctx=8192, pool_tokens=tot + bs * nd + 8, dtype=dtype, device=DEV, fill_kv=True)
+    runner.token_to_kv_pool = H.make_kv_pool(tot + bs * nd + 8, 1, Hkv, D, dtype, DEV, fill_random=True)
+    runner.server_args.speculative_num_draft_tokens = nd
+    backend = MiAttnBackend(runner)
+    g = torch.Generator().manual_seed(12)
+    fb = H.make_decode_batch(runner, backend, bs, 0, DEV, seed=3, ragged=torch.tensor(lens))
+    r2t = runner.req_to_token_pool.req_to_token
+    new_loc = torch.arange(tot + 1, tot + 1 + bs * nd, dtype=torch.int64)
+    for i in range(bs):                                     # the draft nodes' slots follow the committed sequence
+        r2t[i, lens[i]: lens[i] + nd] = new_loc[i * nd: (i + 1) * nd].to(torch.int32).to(DEV)
+    masks, mptr = [], [0]
+    for i in range(bs):
+        S = lens[i] + nd
+        m = torch.ones(nd, S, dtype=torch.bool)
+        m[:, lens[i]:] = torch.rand(nd, nd, generator=g) < 0.5
+        m[torch.arange(nd), lens[i] + torch.arange(nd)] = True
+        masks.append(m.reshape(-1)); mptr.append(mptr[-1] + nd * S)
+    custom_mask = torch.cat(masks)
+    fb.forward_mode = H.ForwardMode.TARGET_VERIFY
+    fb.spec_info = SimpleNamespace(custom_mask=custom_mask.to(DEV))
+    fb.out_cache_loc = new_loc.to(DEV)
+    backend.init_forward_metadata(fb)
+    assert backend.forward_metadata.num_kv_splits > 1
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    q = torch.randn(bs * nd, Hq * D, generator=g).to(dtype)
+    k = torch.randn(bs * nd, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(bs * nd, Hkv, D, generator=g).to(dtype)
+    o = backend.forward(q.to(DEV), k.to(DEV), v.to(DEV), layer, fb)
+    pool = runner.token_to_kv_pool
+    kc, vc = pool.k_buffer[0].cpu(), pool.v_buffer[0].cpu()
+    assert torch.equal(kc[new_loc], k) and torch.equal(vc[new_loc], v)
+    sl = torch.tensor(lens)
+    ref = oa.extend_fp32(q.view(-1, Hq, D), kc, vc, r2t.cpu(), fb.req_pool_indices.cpu(), sl + nd, sl,
+                         torch.full((bs,), nd), D ** -0.5, causal=True, custom_mask=custom_mask,
+                         mask_indptr=torch.tensor(mptr, dtype=torch.int64), skip_prefix_custom_mask=True)
+    torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=4e-3, rtol=2 ** -6)

@@ -211,6 +211,11 @@ def test_extend_attention_fp8_prefix_vs_oracle(dtype, k_scale, v_scale, cap, cau
                                qo, kvp, idx, max(ext), D ** -0.5, cap, causal, -1)
     torch.cuda.synchronize()
     torch.testing.assert_close(o.cpu().float(), ref, atol=2e-2 * max(1.0, v_scale), rtol=2e-2)
+    o2 = torch.empty_like(o)          # split-KV form over the fp8 pool
+    ops.extend_attention_splitkv(q.to(DEV), k.to(DEV), v.to(DEV), o2, k8.to(DEV), v8.view(torch.uint8).to(DEV), qo, kvp, idx,
+                                 max(ext), D ** -0.5, 3, None, cap, causal, -1, k_scale, v_scale)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o2.cpu().float(), ref, atol=2e-2 * max(1.0, v_scale), rtol=2e-2)
 
 
 def test_fp8kv_full_size_constant_v_identity():

@@ -30,7 +30,10 @@ if os.environ.get("GEMM", "1") == "1":
         print(f"fp8_gemm M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
 if os.environ.get("ATTN", "1") == "1":
     Hq, Hkv, D = 32, 8, 128
-    for B, S, P in [(8, 2048, 0), (2, 8192, 0), (8, 512, 1536), (64, 1, 2047)]:
+    cases = [(8, 2048, 0), (2, 8192, 0), (8, 512, 1536), (64, 1, 2047)]
+    if os.environ.get("CASES"):      # e.g. CASES="1x512x32000,4x8x8192" (requests x new tokens x cached prefix)
+        cases = [tuple(int(v) for v in c.split("x")) for c in os.environ["CASES"].split(",")]
+    for B, S, P in cases:
         E = B * S
         q = torch.randn(E, Hq, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
         k = torch.randn(E, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
@@ -43,8 +46,13 @@ if os.environ.get("ATTN", "1") == "1":
         pre = torch.full((B,), P, dtype=torch.int32, device=dev)
         qo = ops.kv_indptr(ext); kvp = ops.kv_indptr(pre).clone()
         idx = (torch.randperm(max(B * P, 1), device=dev).to(torch.int32) + 1)
+        xs = int(os.environ.get("XSPLITS", "1"))
+        wsx = torch.empty(max(1, ops.decode_workspace_numel(E, Hq, D, xs)), dtype=torch.float32, device=dev)
         def run():
-            ops.extend_attention(q, k, v, o, kb, vb, qo, kvp, idx, S, 1 / math.sqrt(D), 0.0, True, -1)
+            if xs > 1:
+                ops.extend_attention_splitkv(q, k, v, o, kb, vb, qo, kvp, idx, S, 1 / math.sqrt(D), xs, wsx)
+            else:
+                ops.extend_attention(q, k, v, o, kb, vb, qo, kvp, idx, S, 1 / math.sqrt(D), 0.0, True, -1)
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 3
