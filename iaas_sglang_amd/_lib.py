@@ -96,8 +96,8 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name} (ABI mismatch with include/mi_hotpath.h)")
         fn.restype = res
         fn.argtypes = args
-    if lib.mi_abi_version() != 4:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != 4")
+    if lib.mi_abi_version() != 5:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != 5")
     return lib
 
 

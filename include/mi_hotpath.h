@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
