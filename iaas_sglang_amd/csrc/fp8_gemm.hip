@@ -766,6 +766,7 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
 // streaming (256 + 256) x K bytes through ONE CU's ~42 GB/s LDS-DMA path (measured: 199 us for 256 x 4096 x 14336,
 // against 24 us at M = 128).  Until the tile grid fills the chip it is cheaper to run the x-stationary decode
 // kernel once per chunk of rows, all 256 CUs busy each time.  Cost model in us, from the measured rates.
+static double tile_time(int64_t M, int64_t N, int64_t K, int* S_out);
 // rows one pass of the decode kernels takes: 256 with the 8-wave deep-ring kernel (MT = 16), else 128
 MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N) {
   static const int deep = xs_env("MI_GEMM_XD", 1), wide = xs_env("MI_GEMM_XD16", 1);
@@ -774,15 +775,18 @@ MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N) {
 static bool mid_m_chunked(int64_t M, int64_t N, int64_t K) {
   if (M <= 128 || M > 1024 || K % 128 != 0) return false;
   const int64_t rows = mi_fp8_gemm_partial_max_rows(N);
-  const double tiles = (double)(cdiv64(M, 256) * cdiv64(N, 256));
-  const double t_tile = (double)cdiv64((int64_t)tiles, 256) * (512.0 * (double)K / 42e3) + 5.0;
+  const double t_tile = tile_time(M, N, K, nullptr);   // with its own split-K where that pays
   const double t_chunk = (double)cdiv64(M, rows) * ((double)N * (double)K / 3.5e6 + 10.0) * (rows == 256 ? 1.5 : 1.0);
   return t_chunk < t_tile;
 }
 
+static int tile_splits(int64_t M, int64_t N, int64_t K);
 extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || K % 128 != 0) return 0;
-  if (M > 128 && !mid_m_chunked(M, N, K)) return 0;
+  if (M > 128 && !mid_m_chunked(M, N, K)) {
+    const int S = tile_splits(M, N, K);
+    return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+  }
   if (M > mi_fp8_gemm_partial_max_rows(N)) M = mi_fp8_gemm_partial_max_rows(N);   // chunks reuse the same slabs
   int S, spw;
   xs_plan(N, K, &S, &spw);
@@ -808,7 +812,8 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
 // load (L2 hits + 24 % from the Infinity Cache), the MMA of a k-step ~0.85 us, and 160 KiB of LDS hold only
 // two 64-KiB stages -- one stage in flight.  Next: finer ring units (quarter stages) or a 4-wave x 2 form.
 template <typename OutT>
-__global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks) {
+__global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks,
+                                                            float* __restrict__ slab, int S) {
   constexpr int BM = 256, BN = 256, BK = 128;
   constexpr int TILE = BM * BK;            // 32 KiB per operand per stage
   constexpr int STAGE = 2 * TILE;          // x tile then w tile
@@ -833,7 +838,13 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const int gsz = min(mblocks - first_m, GM);
   const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
   const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * BN;
-  const int64_t KT = p.K / BK;
+  // split-K (grid.y = S > 1): this workgroup walks k-steps [kt0, KT) of its tile and leaves raw fp32 partials in
+  // slab[blockIdx.y]; fp8_gemm_reduce_kernel sums them and applies the epilogue.  For grids that leave most CUs idle
+  // (1-2 k tokens on a 4096-wide, K = 14336 down projection: 64-128 tiles, each a 112-step serial walk)
+  const int64_t KT_all = p.K / BK;
+  const int64_t kt_per = (KT_all + S - 1) / S;
+  const int64_t kt0 = (int64_t)blockIdx.y * kt_per;
+  const int64_t KT = min(KT_all, kt0 + kt_per);
 
   // DMA geometry: piece i (0..31 per operand) covers tile rows 8i..8i+7; lane L -> LDS byte i*1024 + L*16.
   // LDS line pair l = row>>1, position P = L & 15 within it holds logical (rowbit, slot) = P ^ (l & 15).
@@ -865,11 +876,11 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TL_STAGE(0, 0);
+  if (kt0 < KT) TL_STAGE(kt0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int64_t kt = 0; kt < KT; ++kt) {
-    const int buf = (int)(kt & 1);
+  for (int64_t kt = kt0; kt < KT; ++kt) {
+    const int buf = (int)((kt - kt0) & 1);
     if (kt + 1 < KT) TL_STAGE(kt + 1, buf ^ 1);
     const char* xb = smem + buf * STAGE;
     const char* wb = xb + TILE;
@@ -896,6 +907,27 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #undef TL_FRAG
 
   // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
+  if (S > 1) {
+    float* sb = slab + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 16 + r16;
+        if (m >= p.M) continue;
+        float* o = sb + m * p.N + nbase;
+        if (nbase + 3 < p.N && (p.N & 3) == 0) {
+          *(f32x4*)o = acc[i][j];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nbase + r < p.N) o[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
@@ -927,9 +959,38 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 }
 
 
-template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_t st) {
+// split-K factor of the tile kernel, from the measured rates (us): a k-step of one workgroup costs ~1.3 us of LDS-DMA
+// ingest whatever else runs, the slabs cost a write and a read of S * M * N fp32 at ~4 TB/s
+static double tile_time(int64_t M, int64_t N, int64_t K, int* S_out) {
+  static const int enable = xs_env("MI_GEMM_TILE_SPLITK", 1);
+  const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256), steps = K / 128;
+  int best = 1;
+  double best_t = (double)cdiv64(tiles, 256) * (double)steps * 1.3 + 5.0;
+  if (enable && tiles < 192 && steps >= 32) {
+    for (int s = 2; s <= 4 && tiles * s <= 256 && steps / s >= 16; ++s) {
+      const double t = (double)cdiv64(steps, s) * 1.3 + (double)s * (double)M * (double)N * 8.0 / 4e6 + 10.0;
+      if (t < best_t) { best_t = t; best = s; }
+    }
+  }
+  if (S_out) *S_out = best;
+  return best_t;
+}
+static int tile_splits(int64_t M, int64_t N, int64_t K) {
+  int S;
+  tile_time(M, N, K, &S);
+  return S;
+}
+
+template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
   const int mblocks = (int)cdiv64(p.M, 256), nblocks = (int)cdiv64(p.N, 256);
-  fp8_gemm_tile_kernel<OutT><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks);
+  int S = tile_splits(p.M, p.N, p.K);
+  if (S > 1 && (!workspace || workspace_bytes < (int64_t)S * p.M * p.N * (int64_t)sizeof(float))) S = 1;
+  fp8_gemm_tile_kernel<OutT><<<dim3((unsigned)(mblocks * nblocks), (unsigned)S), 512, 2 * 2 * 256 * 128, st>>>(
+      p, mblocks, nblocks, (float*)workspace, S);
+  if (S > 1) {
+    const int64_t total = p.M * cdiv64(p.N, 4);
+    fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, (const float*)workspace, S);
+  }
 }
 
 template <typename OutT>
@@ -972,7 +1033,7 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     return;
   }
   if (p.K % 128 == 0) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
-    launch_tile<OutT>(p, st);
+    launch_tile<OutT>(p, st, workspace, workspace_bytes);
     return;
   }
   const unsigned gx = (unsigned)cdiv64(p.N, 64);

@@ -76,7 +76,8 @@ def test_fp8_gemm_golden(golden_quant, name):
                                    (2048, 6144, 4096),
                                    # C5 per rank (Llama-3-70B, TP=8, batch 256): qkv, o, gate_up, down
                                    (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584),
-                                   (136, 4096, 4096), (500, 4096, 2048)])          # 128-row chunks: 128 + 8, 3 x 128 + 116
+                                   (136, 4096, 4096), (500, 4096, 2048),           # chunks of rows: 136, 256 + 244
+                                   (1100, 4096, 14336), (2000, 1024, 4096)])       # tile kernel with split-K slabs (S = 4, 2..4)
 @pytest.mark.parametrize("modes", ["tt", "rr", "rt"])
 def test_fp8_gemm_random(M, N, K, modes):
     o_ = ops()
