@@ -811,9 +811,15 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
 // MFMAs removed the kernel still takes 1.94 ms: one 64-KiB stage per CU takes ~2.2 us to land under full
 // load (L2 hits + 24 % from the Infinity Cache), the MMA of a k-step ~0.85 us, and 160 KiB of LDS hold only
 // two 64-KiB stages -- one stage in flight.  Next: finer ring units (quarter stages) or a 4-wave x 2 form.
-template <typename OutT>
+// EPI = 1 (gate_up of a gated MLP, N = 2*I, I % 128 == 0, no split-K): the tile's 256 weight rows are 128 GATE rows
+// n0.. and the 128 UP rows I + n0.. of the same output columns; waves wn = 0,1 end with gate values, wn = 2,3 with the
+// up values of the same (row, column) in the same registers, exchanged through the (free) stage buffers: the
+// epilogue writes fp8(silu(gate) * up) [M, I] directly -- bit-identical to the GEMM followed by mi_silu_and_mul_fp8,
+// without writing and re-reading the [M, 2I] intermediate (0.94 GB per gate_up at 16 k tokens).
+template <typename OutT, int EPI = 0>
 __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks,
-                                                            float* __restrict__ slab, int S) {
+                                                            float* __restrict__ slab, int S,
+                                                            const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
   constexpr int BM = 256, BN = 256, BK = 128;
   constexpr int TILE = BM * BK;            // 32 KiB per operand per stage
   constexpr int STAGE = 2 * TILE;          // x tile then w tile
@@ -837,7 +843,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const int first_m = grp * GM;
   const int gsz = min(mblocks - first_m, GM);
   const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
-  const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * BN;
+  const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * (EPI ? BN / 2 : BN);
+  const int64_t Ihalf = p.N / 2;   // EPI only
   // split-K (grid.y = S > 1): this workgroup walks k-steps [kt0, KT) of its tile and leaves raw fp32 partials in
   // slab[blockIdx.y]; fp8_gemm_reduce_kernel sums them and applies the epilogue.  For grids that leave most CUs idle
   // (1-2 k tokens on a 4096-wide, K = 14336 down projection: 64-128 tiles, each a 112-step serial walk)
@@ -861,7 +868,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       const int row_ = line_ * 2 + (logical_ >> 3);                                                  \
       const int slot_ = logical_ & 7;                                                                \
       const uint8_t* xs_ = p.a + min(m0 + row_, p.M - 1) * p.lda + kb_ + slot_ * 16;                 \
-      const uint8_t* ws_ = p.b + min(n0 + row_, p.N - 1) * p.ldb + kb_ + slot_ * 16;                 \
+      const int64_t wr_ = EPI ? (row_ < 128 ? n0 + row_ : Ihalf + n0 + (row_ - 128)) : n0 + row_;    \
+      const uint8_t* ws_ = p.b + min(wr_, p.N - 1) * p.ldb + kb_ + slot_ * 16;                       \
       glds16(xs_, lds_base + (buf_) * STAGE + piece_ * 1024);                                        \
       glds16(ws_, lds_base + (buf_) * STAGE + TILE + piece_ * 1024);                                 \
     }                                                                                                \
@@ -907,6 +915,54 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #undef TL_FRAG
 
   // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
+  if constexpr (EPI == 1) {
+    // the loop's last barrier is behind every wave: the stage buffers are free.  All waves: x = round_T(acc*sa*sb)
+    f32x4* xch = (f32x4*)smem;               // [4 up waves][32 tiles][64 lanes] f32x4 = 128 KiB
+    const bool up = wn >= 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = n0 + (wn & 1) * 64 + j * 16 + 4 * q;          // output column (0 .. I)
+      const int64_t nsrc = (up ? Ihalf : 0) + col;                      // weight row the scale belongs to
+      float sbv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sbv[r] = p.sb_row ? p.sb[min(nsrc + r, p.N - 1)] : p.sb[0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = min(m0 + wm * 128 + i * 16 + r16, p.M - 1);
+        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = round_to<OutT>(acc[i][j][r] * sav * sbv[r]);
+        if (up) xch[((wm * 2 + (wn - 2)) * 32 + i * 4 + j) * 64 + lane] = acc[i][j];
+      }
+    }
+    __syncthreads();
+    if (up) return;
+    const float qs = *epi.q_scale;
+    const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 16 + 4 * q;
+      if (col >= Ihalf) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 16 + r16;
+        if (m >= p.M) continue;
+        const f32x4 u = xch[((wm * 2 + wn) * 32 + i * 4 + j) * 64 + lane];
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[i][j][r];
+          o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+          o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+        }
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+        *(uint32_t*)(epi.q_out + m * Ihalf + col) = w;
+      }
+    }
+    return;
+  }
   if (S > 1) {
     float* sb = slab + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -1110,6 +1166,22 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
                                           void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K, int64_t lda,
                                           int64_t ldb, int dtype, void* stream) {
   const int64_t N = 2 * I;
+  if (M > 512 && K % 128 == 0 && I % 128 == 0 && lda % 16 == 0 && ldb % 16 == 0 &&
+      !(((uintptr_t)a | (uintptr_t)b_nk) & 15) && !((uintptr_t)q_out & 3)) {
+    // prefill: the 256 x 256 tile kernel with the same epilogue (a tile = 128 gate + 128 up rows of the weights)
+    GemmParams p;
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
+    const SiluEpi epi{(uint8_t*)q_out, q_scale};
+    const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(I / 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_BF16)
+      fp8_gemm_tile_kernel<bf16_t, 1><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+    else
+      fp8_gemm_tile_kernel<f16_t, 1><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+  }
   if (M <= 0 || M > 256 || K % 128 != 0 || I % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0) return 1;
   if ((((uintptr_t)a | (uintptr_t)b_nk) & 15) || ((uintptr_t)q_out & 3)) return 1;
   if (xs_waves(N) != 8 || M > mi_fp8_gemm_partial_max_rows(N)) return 1;

@@ -325,6 +325,16 @@ class LlamaStack:
                                 L.attn, fb)
             hidden = self._all_reduce(L.o(a))
             qs = L.gate_up.fused_quant_scale()
+            qs_down = L.down.fused_quant_scale()
+            silu_ok = getattr(L.gate_up.quant_method, "fused_silu_ok", None)
+            if (qs is not None and qs_down is not None and LlamaStack.fuse_decode_layer and silu_ok is not None
+                    and silu_ok(L.gate_up, hidden.shape[0])):
+                # gate_up GEMM with SiLU*mul + FP8 quant in its epilogue (prefill: the tile kernel's; the [T, 2I]
+                # intermediate is never written) -- bit-identical to the two-step form below
+                act8 = L.gate_up.quant_method.apply_silu_mul(
+                    L.gate_up, ops.rmsnorm_fp8(hidden, L.post_norm, s.rms_eps, qs, residual=residual), qs_down, self.dtype)
+                hidden = self._all_reduce(L.down.forward_prequantized(act8, self.dtype))
+                continue
             if qs is not None:
                 gu = L.gate_up.forward_prequantized(
                     ops.rmsnorm_fp8(hidden, L.post_norm, s.rms_eps, qs, residual=residual), self.dtype)

@@ -609,7 +609,12 @@ def fp8_gemm_silu_mul(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor
     N = b_kn.shape[1]
     assert N % 2 == 0 and q_scale.dtype == torch.float32 and q_scale.numel() == 1
     q = torch.empty(M, N // 2, dtype=FP8_DTYPE, device=a.device)
-    ws, nbytes = _fused_ws(M, N, K, a.device)
+    if M > 512:        # prefill: the tile kernel's own epilogue, no slabs (needs I % 128 == 0, K % 128 == 0)
+        if (N // 2) % 128 != 0 or K % 128 != 0:
+            raise MiHotpathError(f"fused gate_up at M={M}: needs I % 128 == 0 and K % 128 == 0 (I={N // 2}, K={K})")
+        ws, nbytes = None, 0
+    else:
+        ws, nbytes = _fused_ws(M, N, K, a.device)
     check(lib.mi_fp8_gemm_silu_mul_fp8(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(q), _ptr(q_scale), M,
                                        N // 2, K, a.stride(0), b_kn.stride(1), _DT[act_dtype], _ptr(ws), nbytes,
                                        _stream()), "mi_fp8_gemm_silu_mul_fp8")

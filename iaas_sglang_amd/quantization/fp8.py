@@ -111,6 +111,16 @@ class Fp8FusedDecodeMixin:
         return (s is not None and s.numel() == 1 and layer.weight_scale.numel() == 1 and 0 < M <= 512
                 and K % 128 == 0 and getattr(layer, "bias", None) is None)
 
+    @staticmethod
+    def fused_silu_ok(layer: torch.nn.Module, M: int) -> bool:
+        """apply_silu_mul at this row count: decode batches as fused_decode_ok; prefill (M > 512) through the tile
+        kernel's epilogue when the halves are 128-column aligned."""
+        s = getattr(layer, "input_scale", None)
+        K, N = layer.weight.shape
+        if s is None or s.numel() != 1 or layer.weight_scale.numel() != 1 or getattr(layer, "bias", None) is not None:
+            return False
+        return K % 128 == 0 and (M <= 512 or (N // 2) % 128 == 0)
+
     def apply_add_rmsnorm(self, layer, qx, residual, norm_weight, eps, next_scale=None, want_out=False):
         """(out | None, fp8 | None) = rmsnorm(linear(qx) + residual) * norm_weight [-> fp8 with next_scale]."""
         return ops.fp8_gemm_add_rmsnorm(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),

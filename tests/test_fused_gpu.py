@@ -78,7 +78,8 @@ def test_gemm_rope_kvwrite_bit_identical(M, Hq, Hkv, D, K, dtype):
 
 
 @pytest.mark.parametrize("M,I,K", [(128, 14336, 4096), (77, 14336, 4096), (128, 1792, 4096), (3, 512, 256), (16, 64, 128),
-                                   (128, 1000 * 8, 512)])
+                                   (128, 1000 * 8, 512),
+                                   (2048, 14336, 1024), (700, 1792, 4096), (513, 128, 128)])   # prefill: tile-kernel epilogue
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_silu_mul_fp8_bit_identical(M, I, K, dtype):
     """Covers both routes: the in-kernel epilogue (N large, no split-K: 14336) and the slab consumer."""
@@ -90,7 +91,14 @@ def test_gemm_silu_mul_fp8_bit_identical(M, I, K, dtype):
     q1 = ops.silu_and_mul_fp8(gu, qscale)
     q2 = ops.fp8_gemm_silu_mul(qx, w, xs, ws, qscale, dtype)
     torch.cuda.synchronize()
-    assert torch.equal(_bits(q1), _bits(q2))
+    if M <= 512:
+        assert torch.equal(_bits(q1), _bits(q2))
+    else:
+        # prefill: same tile kernel, but the unfused call may pick split-K slabs (another fp32 summation order), so a
+        # few values land on the neighbouring T / fp8 code
+        diff = (_bits(q1) != _bits(q2)).float().mean().item()
+        assert diff < 5e-3, diff
+        torch.testing.assert_close(q2.float(), q1.float(), rtol=0.13, atol=2 ** -6)
     assert int((_bits(q1) != 0).sum()) > q1.numel() // 4      # not a trivially-zero comparison
 
 
@@ -225,9 +233,12 @@ def test_fused_entry_points_reject_bad_arguments():
     from iaas_sglang_amd import ops
     from iaas_sglang_amd._lib import MiHotpathError
     g = torch.Generator().manual_seed(0)
-    qx, w, xs, ws = _fp8_operands(600, 256, 256, g)          # M > 512: not a decode shape
+    qx, w, xs, ws = _fp8_operands(600, 128, 256, g)          # M > 512 and I = 64: neither a decode shape nor tile-aligned halves
     with pytest.raises(MiHotpathError):
         ops.fp8_gemm_silu_mul(qx, w, xs, ws, torch.tensor([0.05], device=DEV), torch.bfloat16)
+    qx, w, xs, ws = _fp8_operands(600, 256, 256, g)          # the slab consumers are decode forms: M <= 512
+    with pytest.raises(MiHotpathError):
+        ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, None, torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-5)
     qx, w, xs, ws = _fp8_operands(8, 256, 192, g)            # K % 128 != 0
     with pytest.raises(MiHotpathError):
         ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, None, torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-5)
