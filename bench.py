@@ -336,7 +336,7 @@ def main():
                            kv_dtype=torch.float8_e4m3fn if kv8 else None)
     backend = MiAttnBackend(runner)
     if a.splits:
-        backend._choose_splits = lambda bs, tot: a.splits
+        backend._choose_splits = lambda bs, tot, cap=None: a.splits
     custom_ar = make_custom_ar(world, rank, dev, B * shape.hidden * 2) if not a.no_custom_ar else None
     static = a.act_scheme == "static"
     cfg = Fp8Config(is_checkpoint_fp8_serialized=static, activation_scheme=a.act_scheme)
