@@ -115,17 +115,19 @@ class MiAttnBackend(AttentionBackend):
         workgroup doing the same work, so the time is  rounds x (keys per split + a fixed ramp) + the merge:
         pick the split count that minimises it -- i.e. a workgroup count that fills whole rounds of the
         chip (measured at B=128, S=2048: 2 splits = 256 workgroups 183 us, 3 splits 223 us, 4 splits
-        194 us).  Never below ~256 keys per split (512 beyond the serving cap: the merge walks the splits
-        serially, ~0.75 us each).  Any value gives the same math up to fp32 reassociation."""
+        194 us).  Never below 128 keys per split: a lone workgroup walks its keys at ~21 keys/us (dependent
+        index -> row loads), so small batches want many short splits (B=1, S=2048: 8 splits 25.8 us, 16 splits
+        19.7 us, 64 splits 22.0 us -- the merge costs ~0.13 us per split).  Any value gives the same math up to fp32
+        reassociation."""
         heads_per_wg = self._heads_per_wg()
         wgs = bs * (self.num_kv_head // heads_per_wg)
         slots = self.cu_count * max(1, 8 // heads_per_wg)        # co-resident workgroups on the chip
         avg = max(seq_lens_sum // max(bs, 1), 1)
-        ramp, merge = 96, 4.7                                   # launch + first-tile latency / merge step, in keys
+        ramp, merge = 96, 0.8                                   # launch + first-tile latency / merge step, in keys
         cap = self._split_cap(bs) if cap is None else cap
         best, best_cost = 1, None
         for s in range(1, max(1, cap) + 1):
-            if s > 1 and (avg // s < 256 or (s > self.max_kv_splits and avg // s < 512)):
+            if s > 1 and avg // s < 128:
                 break
             rounds = -(-wgs * s // slots)
             cost = rounds * (-(-avg // s) + ramp) + merge * s

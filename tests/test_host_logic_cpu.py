@@ -79,7 +79,8 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     assert be._choose_splits(1, 100) == 1                    # never split below ~256 keys
     assert be._choose_splits(1, 100000) == 64                # a few long requests: beyond the serving cap, to reach every CU
     assert be._choose_splits(1, 100000, cap=8) == 8          # ... unless the caller's buffers cap it
-    assert be._choose_splits(8, 8 * 8192) == 16              # >= 512 keys per split beyond --triton-attention-num-kv-splits
+    assert be._choose_splits(8, 8 * 8192) == 32              # 8 x 32 = 256 workgroups of 256 keys: one round
+    assert be._choose_splits(1, 2048) == 16                  # a lone request: many short splits (>= 128 keys each)
     assert be._choose_splits(32, 32 * 4096) == 8
     assert be._split_cap(1) == 64 and be._split_cap(32) == 16 and be._split_cap(128) == 8
     assert be._choose_splits(4096, 4096 * 512) == 1          # enough requests: no split
