@@ -216,6 +216,19 @@ def test_extend_attention_fp8_prefix_vs_oracle(dtype, k_scale, v_scale, cap, cau
                                  max(ext), D ** -0.5, 3, None, cap, causal, -1, k_scale, v_scale)
     torch.cuda.synchronize()
     torch.testing.assert_close(o2.cpu().float(), ref, atol=2e-2 * max(1.0, v_scale), rtol=2e-2)
+    if causal:       # tree mask over an fp8 pool (TARGET_VERIFY with --kv-cache-dtype fp8): a lower-triangular mask == causal
+        masks, mptr = [], [0]
+        for i in range(B):
+            m = torch.ones(ext[i], pre[i] + ext[i], dtype=torch.bool)
+            m[:, pre[i]:] = torch.tril(torch.ones(ext[i], ext[i], dtype=torch.bool))
+            masks.append(m.reshape(-1)); mptr.append(mptr[-1] + m.numel())
+        for splits in (1, 3):
+            o3 = torch.empty_like(o)
+            ops.extend_attention_splitkv(q.to(DEV), k.to(DEV), v.to(DEV), o3, k8.to(DEV), v8.view(torch.uint8).to(DEV), qo, kvp,
+                                         idx, max(ext), D ** -0.5, splits, None, cap, True, -1, k_scale, v_scale,
+                                         torch.cat(masks).to(DEV), torch.tensor(mptr, dtype=torch.int64, device=DEV), True)
+            torch.cuda.synchronize()
+            torch.testing.assert_close(o3.cpu().float(), ref, atol=2e-2 * max(1.0, v_scale), rtol=2e-2)
 
 
 def test_fp8kv_full_size_constant_v_identity():
