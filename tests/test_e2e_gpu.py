@@ -162,6 +162,25 @@ def test_backend_graph_capture_replay_matches_eager(ctx, trials):
         eager_backend.init_forward_metadata(fb2)
         want = eager_backend.forward(q, k, v, layer, fb2)     # KV write is idempotent (same k,v,slots)
         torch.testing.assert_close(got.float(), want.float(), atol=4e-3, rtol=2 ** -7)
+    # back-to-back replays WITHOUT host syncs in between: every replay must see its own plan (the pinned staging
+    # buffers rotate; a plan overwritten before its copy ran would show up as a wrong result)
+    gots = []
+    qs = torch.randn(q.shape, generator=g).to(dtype).to(DEV)
+    q.copy_(qs)
+    for it in range(12):
+        lens = torch.randint(1, ctx - 1, (bs,), generator=torch.Generator().manual_seed(500 + it)).tolist()
+        fbk = H.make_decode_batch(runner, MiAttnBackend(runner), bs, 0, DEV, seed=100 + it, ragged=torch.tensor(lens))
+        rpi.copy_(fbk.req_pool_indices); seq_lens.copy_(fbk.seq_lens); out_loc.copy_(fbk.out_cache_loc)
+        backend.init_forward_metadata_replay_cuda_graph(bs, rpi, seq_lens, sum(lens), None, H.ForwardMode.DECODE, None,
+                                                        fbk.seq_lens_cpu)
+        graph.replay()
+        gots.append(out.clone())                              # stream-ordered, no sync
+        eb = fbk.attn_backend
+        eb.init_forward_metadata(fbk)
+        gots.append(eb.forward(q, k, v, layer, fbk))          # eager result for the same inputs, also enqueued now
+    torch.cuda.synchronize()
+    for it in range(12):
+        torch.testing.assert_close(gots[2 * it].float(), gots[2 * it + 1].float(), atol=4e-3, rtol=2 ** -7)
 
 
 def _extend_then_decode(stack, runner, backend, shape, dtype, W, lin, prefix, extend, tol, decode_steps=2):
