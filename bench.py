@@ -95,7 +95,16 @@ def make_custom_ar(world, rank, dev, msg_bytes):
     y = ca.all_reduce(x)
     torch.cuda.synchronize()
     ok = bool(torch.equal(y, ref)) and not ca.timed_out()
-    if ok:      # the fused all-reduce + add + RMSNorm + fp8 form must give the bits of the unfused sequence
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)       # every rank takes the same branch below
+    if int(flag.item()) != 1:
+        if rank == 0:
+            print("[bench] native all-reduce self-check failed; using RCCL", file=sys.stderr)
+        return None
+    # the fused all-reduce + add + RMSNorm + fp8 form, fed from the registered staging buffer as the step feeds it, must
+    # give the bits of the unfused sequence; any local problem (an exception included) switches it off on every rank
+    fused = 1
+    try:
         from iaas_sglang_amd import ops
         rows, Hh = max(1, msg_bytes // 2 // 4096), 4096
         gc = torch.Generator(device=dev).manual_seed(7)
@@ -105,21 +114,20 @@ def make_custom_ar(world, rank, dev, msg_bytes):
         qs = torch.tensor([0.02], device=dev)
         r1, r2 = res.clone(), res.clone()
         want = ops.rmsnorm_fp8(ca.all_reduce(xs), w, 1e-5, qs, residual=r1)
-        _, got = ca.all_reduce_add_rmsnorm(xs, r2, w, 1e-5, q_scale=qs, want_out=False)
+        buf = ca.staging((rows, Hh), torch.bfloat16)
+        buf.copy_(xs)
+        _, got = ca.all_reduce_add_rmsnorm(buf, r2, w, 1e-5, q_scale=qs, want_out=False)
         torch.cuda.synchronize()
-        fused_ok = torch.tensor([int(torch.equal(got.view(torch.uint8), want.view(torch.uint8)) and torch.equal(r1, r2)
-                                     and not ca.timed_out())], device=dev)
-        torch.distributed.all_reduce(fused_ok, op=torch.distributed.ReduceOp.MIN)
-        if int(fused_ok.item()) != 1:
-            ca.fuse_norm = False
-            if rank == 0:
-                print("[bench] fused all-reduce+norm self-check failed; using the unfused sequence", file=sys.stderr)
-    flag = torch.tensor([1 if ok else 0], device=dev)
-    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-    if int(flag.item()) != 1:
+        fused = int(torch.equal(got.view(torch.uint8), want.view(torch.uint8)) and torch.equal(r1, r2) and not ca.timed_out())
+    except Exception as e:  # noqa: BLE001
+        fused = 0
+        print(f"[bench] rank {rank}: fused all-reduce+norm self-check raised {type(e).__name__}: {e}", file=sys.stderr)
+    fused_ok = torch.tensor([fused], device=dev)
+    torch.distributed.all_reduce(fused_ok, op=torch.distributed.ReduceOp.MIN)
+    if int(fused_ok.item()) != 1:
+        ca.fuse_norm = False
         if rank == 0:
-            print("[bench] native all-reduce self-check failed; using RCCL", file=sys.stderr)
-        return None
+            print("[bench] fused all-reduce+norm self-check failed; using the unfused sequence", file=sys.stderr)
     return ca
 
 
