@@ -144,9 +144,14 @@ __global__ __launch_bounds__(256) void rope_neox_kernel(T* __restrict__ q, T* __
   float x1[8], x2[8], o1[8], o2[8];
   unpack8f<T>(*(const uint4*)(base + c * 8), x1);
   unpack8f<T>(*(const uint4*)(base + half + c * 8), x2);
+  // cos / sin of the 8 pairs as four 16-byte loads (rows of the cache are D floats: 16-byte aligned for D % 16 == 0)
+  const f32x4 c0 = *(const f32x4*)(cs + c * 8), c1 = *(const f32x4*)(cs + c * 8 + 4);
+  const f32x4 s0 = *(const f32x4*)(cs + half + c * 8), s1 = *(const f32x4*)(cs + half + c * 8 + 4);
+  const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+  const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float co = rnd<T>(cs[c * 8 + j]), si = rnd<T>(cs[half + c * 8 + j]);
+    const float co = rnd<T>(cv[j]), si = rnd<T>(sv[j]);
     o1[j] = rnd<T>(rnd<T>(x1[j] * co) - rnd<T>(x2[j] * si));
     o2[j] = rnd<T>(rnd<T>(x2[j] * co) + rnd<T>(x1[j] * si));
   }
@@ -159,7 +164,7 @@ extern "C" int mi_rope_neox(void* q, void* k, const int64_t* positions, const fl
                             int64_t ldq, int64_t ldk, int dtype, void* stream) {
   MI_CHECK_ARG(tokens >= 0);
   if (tokens == 0) return MI_OK;
-  MI_CHECK_ARG(q && k && positions && cos_sin_cache);
+  MI_CHECK_ARG(q && k && positions && cos_sin_cache && ((uintptr_t)cos_sin_cache & 15) == 0);
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (head_dim % 16 != 0 || ldq % 8 || ldk % 8)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_rope_neox: head_dim must be a multiple of 16");

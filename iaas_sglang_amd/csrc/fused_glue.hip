@@ -175,9 +175,13 @@ __global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __r
   for (int j = 0; j < 8; ++j) { x1[j] = rndT<T>(acc1[j] * sa[0] * sb[0]); x2[j] = rndT<T>(acc2[j] * sa[0] * sb[0]); }
   if (h < Hq + Hkv) {  // q or k head: rotate
     const float* cs = cos_sin + positions[t] * D;
+    const f32x4 c0 = *(const f32x4*)(cs + c * 8), c1 = *(const f32x4*)(cs + c * 8 + 4);
+    const f32x4 s0 = *(const f32x4*)(cs + half + c * 8), s1 = *(const f32x4*)(cs + half + c * 8 + 4);
+    const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float co = rndT<T>(cs[c * 8 + j]), si = rndT<T>(cs[half + c * 8 + j]);
+      const float co = rndT<T>(cv[j]), si = rndT<T>(sv[j]);
       o1[j] = rndT<T>(rndT<T>(x1[j] * co) - rndT<T>(x2[j] * si));
       o2[j] = rndT<T>(rndT<T>(x2[j] * co) + rndT<T>(x1[j] * si));
     }
@@ -311,6 +315,7 @@ extern "C" int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const f
   const int64_t N = (num_q_heads + 2 * num_kv_heads) * head_dim;
   FUSED_PROLOGUE("mi_fp8_gemm_rope_kvwrite");
   MI_CHECK_ARG(positions && cos_sin_cache && q_out && k_cache && v_cache && loc && num_q_heads > 0 && num_kv_heads > 0);
+  MI_CHECK_ARG(((uintptr_t)cos_sin_cache & 15) == 0);
   if (head_dim % 16 != 0 || ldq % 8 || cache_stride_k % 8 || cache_stride_v % 8)
     MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_rope_kvwrite: head_dim %% 16 and 16-byte aligned rows required");
   const int rc = mi_fp8_gemm_partial(a, b_nk, (float*)workspace, M, N, K, lda, ldb, stream);
