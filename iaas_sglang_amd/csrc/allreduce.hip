@@ -50,10 +50,10 @@ __device__ __forceinline__ void ar_store_flag(uint32_t* p, uint32_t v, bool rele
 // all ranks arrive; `slots` = start or end array of every rank's signal
 template <bool ACQ_REL>
 __device__ __forceinline__ void ar_barrier(const ArPeers& pr, int rank, int world, bool use_end, uint32_t flag) {
-  if (ACQ_REL) {
-    __syncthreads();
-    __threadfence_system();
-  }
+  // an end barrier says "this workgroup is done reading": every wave must have finished its loads before the flag
+  // goes out (custom_all_reduce_hip.cuh:205 does the same, final sync included); a start barrier has nothing before it
+  if (use_end) __syncthreads();
+  if (ACQ_REL) __threadfence_system();
   ArSignal* self = pr.sig[rank];
   if ((int)threadIdx.x < world) {
     ArSignal* peer = pr.sig[threadIdx.x];
@@ -184,14 +184,25 @@ __global__ __launch_bounds__(AR_THREADS) void ar_add_rmsnorm_kernel(const ArPeer
   __shared__ float red[2][4];
   ArSignal* self = pr.sig[rank];
   const uint32_t flag = self->flag[blockIdx.x] + 1;
-  const int64_t nvec = H / 8, packs = rows * nvec;
-  const int64_t part = packs / world;
+  const int64_t nvec = H / 8;
+  // 2-stage ownership: rank r reduces COLUMN slice r (cpart packs, the last rank takes the remainder) of every row,
+  // and workgroup b of every rank handles the same rows (2b, 2b+1, then + 2*gridDim.x ...) in both phases.  The
+  // packs workgroup b gathers from an owner were therefore written by workgroup b of that owner, which is exactly
+  // what the per-workgroup end barrier orders.  (A flat slice of the message -- what ar_2stage_kernel uses with a
+  // matching gather stride -- would make this row-wise gather read packs other workgroups of the owner wrote.)
+  const int64_t cpart = nvec / world;
   ar_barrier<false>(pr, rank, world, false, flag);
   if (TWO_STAGE) {
-    const int64_t lo = rank * part, hi = (rank == world - 1) ? packs : lo + part;
+    const int64_t clo = rank * cpart, cw = (rank == world - 1) ? nvec - clo : cpart;
+    const int64_t rstep = (int64_t)gridDim.x * 2;
+    const int64_t rb = (int64_t)blockIdx.x * 2;
+    const int64_t npair = rb < rows ? (rows - rb + rstep - 1) / rstep : 0;   // row pairs of this workgroup
     uint4* mytmp = (uint4*)pr.tmp[rank];
-    for (int64_t i = lo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < hi; i += (int64_t)gridDim.x * AR_THREADS)
-      mytmp[i - lo] = ar_reduce_pack<T>(pr, world, i);
+    for (int64_t i = threadIdx.x; i < npair * 2 * cw; i += AR_THREADS) {
+      const int64_t j = i / cw, c = clo + (i - j * cw);
+      const int64_t row = rb + (j >> 1) * rstep + (j & 1);
+      if (row < rows) mytmp[row * nvec + c] = ar_reduce_pack<T>(pr, world, row * nvec + c);
+    }
     ar_barrier<true>(pr, rank, world, true, flag);
   }
   const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
@@ -207,9 +218,9 @@ __global__ __launch_bounds__(AR_THREADS) void ar_add_rmsnorm_kernel(const ArPeer
         const int64_t idx = row * nvec + c;
         uint4 u;
         if (TWO_STAGE) {
-          const int64_t o = idx / part;
+          const int64_t o = c / cpart;
           const int owner = o < world ? (int)o : world - 1;
-          u = ((const uint4*)pr.tmp[owner])[idx - owner * part];
+          u = ((const uint4*)pr.tmp[owner])[idx];
         } else {
           u = ar_reduce_pack<T>(pr, world, idx);
         }
@@ -390,7 +401,7 @@ extern "C" int mi_ar_all_reduce_add_rmsnorm(void* ctx, const void* inp, void* re
     MI_FAIL(MI_ERR_LAUNCH, "mi_ar_all_reduce_add_rmsnorm: staging copy failed");
   const int64_t packs = bytes / 16;
   const bool one_stage = c->world == 2 || (c->world <= 4 && bytes < 512 * 1024) || bytes < 256 * 1024 ||
-                         packs < c->world;
+                         packs < c->world || H / 8 < c->world;
   int blocks = (int)cdiv64(rows, 2);
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   const int vpt = (int)cdiv64(H / 8, 256);

@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   }
   if (active) {
     const int64_t b = bh / num_q_heads, h = bh % num_q_heads;
-    const float inv = out_scale == 1.f ? 1.f / L : out_scale / L;
+    // a zero-length request has no valid split: write zeros, as the unsplit path does (not 0 * inf = NaN)
+    const float inv = !(L > 0.f) ? 0.f : out_scale == 1.f ? 1.f / L : out_scale / L;
     if (o) {
       T* out = o + b * stride_o_tok + h * D + lane * EPL;
 #pragma unroll

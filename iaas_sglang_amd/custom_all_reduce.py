@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from contextlib import contextmanager
 from typing import List, Optional
 
 import torch
@@ -21,6 +22,7 @@ _DT = {torch.bfloat16: MI_BF16, torch.float16: MI_FP16, torch.float32: MI_F32}
 
 class CustomAllreduce:
     _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]          # custom_all_reduce.py:147
+    _IS_CAPTURING = False                          # custom_all_reduce.py:53, set by capture()
 
     def __init__(self, cpu_group: dist.ProcessGroup, device: torch.device, max_size: int = 8 * 1024 * 1024):
         self.disabled = True
@@ -149,9 +151,34 @@ class CustomAllreduce:
         return (self.fuse_norm and not self.disabled and dtype in (torch.bfloat16, torch.float16) and H % 8 == 0 and H <= 16384
                 and rows * H * 2 <= self.max_size)
 
+    @contextmanager
+    def capture(self):
+        """`GroupCoordinator.graph_capture` wraps every hipGraph capture in this (parallel_state.py:377-378;
+        custom_all_reduce.py:336-348).  The reference needs it to collect the addresses of the captured inputs and
+        register them with the peers afterwards; here every captured all-reduce goes through the one persistent
+        IPC-mapped staging buffer (its copy node is part of the graph, or the producer wrote there directly), and the
+        barrier flags live in device memory and only ever grow, so a captured launch replays as it is."""
+        try:
+            self._IS_CAPTURING = True
+            yield
+        finally:
+            self._IS_CAPTURING = False
+            if not self.disabled:
+                self.register_graph_buffers()
+
+    def register_graph_buffers(self) -> int:
+        """custom_all_reduce.py:388-412 exchanges the IPC handles of the buffers recorded during capture.  Nothing was
+        recorded (see capture()); returns the number of addresses registered, always 0."""
+        return 0
+
     def custom_all_reduce(self, inp: torch.Tensor) -> Optional[torch.Tensor]:
-        """None means: fall through to RCCL (parallel_state.py:495-500)."""
-        return self.all_reduce(inp) if self.should_custom_ar(inp) else None
+        """None means: fall through to RCCL (parallel_state.py:495-500).  Inside capture() but outside an actual
+        stream capture (the warm-up run) only the allocation pattern is mimicked, as custom_all_reduce.py:476-485."""
+        if self.disabled or not self.should_custom_ar(inp):
+            return None
+        if self._IS_CAPTURING and not torch.cuda.is_current_stream_capturing():
+            return torch.empty_like(inp)
+        return self.all_reduce(inp)
 
     def timed_out(self) -> bool:
         return (not self.disabled) and lib.mi_ar_error(self._ctx) != 0

@@ -311,14 +311,21 @@ def fp8_quant_per_token(x: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 
 _GEMM_WS = {}
+_GEMM_WS_RETIRED = []      # outgrown buffers stay alive: a captured hipGraph may have their address baked in
 
 
 def _gemm_workspace(nbytes: int, device) -> torch.Tensor:
-    """Split-K scratch, one growing buffer per device; stream-ordered use (calls on one stream are
-    serialised, so consecutive GEMMs may share it; grown outside graph capture by the warm-up run)."""
+    """Split-K scratch, one growing buffer per device; stream-ordered use (calls on one stream are serialised, so
+    consecutive GEMMs may share it).  A buffer that is outgrown is retired, never freed: graphs captured at start-up
+    (decode GEMMs, the fused forms, w4a16) keep writing their slabs to the address they were captured with, and a
+    later eager prefill GEMM that needs more scratch must not hand that memory back to the caching allocator under
+    them.  Growth is geometric, so the retired buffers add up to less than the live one."""
     key = str(device)
     buf = _GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _GEMM_WS_RETIRED.append(buf)
+            nbytes = max(nbytes, 2 * buf.numel())
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _GEMM_WS[key] = buf
     return buf

@@ -236,7 +236,8 @@ def extend_fp32(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens,
 def merge_state(o_a, lse_a, o_b, lse_b):
     """lse-weighted merge of two partial attention results.
     Restates sgl-kernel/csrc/attention/merge_attn_states.cu:63-104
-    (inf lse -> -inf guard, fp32 arithmetic, output in o dtype, lse fp32)."""
+    (inf lse -> -inf guard, fp32 arithmetic, output in o dtype, lse fp32).  Pinned by the reference's
+    `merge_state_torch` (sgl-kernel/tests/test_merge_state_v2.py:101-135) through tests/golden/elementwise.pt."""
     la = torch.where(torch.isinf(lse_a), torch.full_like(lse_a, float("-inf")), lse_a).float()
     lb = torch.where(torch.isinf(lse_b), torch.full_like(lse_b, float("-inf")), lse_b).float()
     m = torch.maximum(la, lb)

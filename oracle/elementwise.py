@@ -2,8 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY.  These are SURVEY section 8f "next" rows; the bodies restate the
 reference's forward_native methods line by line (citations relative to /root/reference).
-No reference-generated golden vector is held for them (the modules import sgl_kernel at
-module level): parity for these three ops is pinned by restatement only.
+PINNED: tests/test_oracle_golden.py asserts every function here bit-identical to the outputs of the
+reference's own forward_native methods (layernorm.py:128, activation.py:56, rotary_embedding.py:138)
+held in tests/golden/elementwise.pt (tests/golden/make_golden_elementwise.py runs them), and within the
+stated tolerance of the sgl-kernel tests' torch forms (test_norm.py, test_rotary_embedding.py).
 """
 import torch
 import torch.nn.functional as F

@@ -68,9 +68,28 @@ def scaled_mm(a_q, b_q, scale_a, scale_b, out_dtype, bias=None):
     return o
 
 
+def per_tensor_dequantize(tensor, inv_scale):
+    """quantization/utils.py:58-63: through fp16, whatever the model dtype."""
+    return tensor.to(torch.float16) * inv_scale
+
+
+def convert_to_channelwise(weight_scale, logical_widths: List[int]):
+    """quantization/utils.py:71-91: one fp32 scale per output channel, [sum(widths), 1]."""
+    out = torch.empty((sum(logical_widths), 1), dtype=torch.float32)
+    if weight_scale.dim() == 0:
+        out.fill_(weight_scale.item())
+        return out
+    start = 0
+    for idx, w in enumerate(logical_widths):
+        out[start:start + w, :] = weight_scale[idx]
+        start += w
+    return out
+
+
 def requantize_with_max_scale(weight, weight_scale, logical_widths: List[int]):
     """Fuse N per-shard scales into one.  Restates quantization/utils.py:94-119
-    (+ per_tensor_dequantize :58-63 which goes through fp16)."""
+    (+ per_tensor_dequantize :58-63 which goes through fp16).  Pinned by running the reference function
+    (tests/golden/make_golden_elementwise.py -> elementwise.pt: unfused and fused-checkpoint cases)."""
     max_w = weight_scale.max()
     unfused = bool(weight_scale[-1] > torch.finfo(FP8).min)
     weight = weight.clone()

@@ -22,3 +22,9 @@ def golden_attention():
 def golden_quant():
     import torch
     return torch.load(os.path.join(ROOT, "tests", "golden", "quant.pt"), weights_only=True)
+
+
+@pytest.fixture(scope="session")
+def golden_elementwise():
+    import torch
+    return torch.load(os.path.join(ROOT, "tests", "golden", "elementwise.pt"), weights_only=True)

@@ -68,6 +68,11 @@ def _worker(rank, world, port, out):
                     res_b = res0.cuda()
                     want_q = ops.rmsnorm_fp8(h, w, 1e-5, qs, residual=res_b)
                     res_c = res0.cuda()
+                    # leave OTHER values in staging and in both tmp layouts first: a fused call that picked up a
+                    # peer's tmp before it was rewritten would otherwise read the very sums it is about to compute
+                    junk = (allx[(rank + 1) % world] * 3 + 1).to(dtype).cuda()
+                    ca.all_reduce(junk)
+                    ca.all_reduce_add_rmsnorm(junk, None, w, 1e-5, want_out=True)
                     if staged:
                         buf.copy_(allx[rank].cuda())
                     got_o, got_q = ca.all_reduce_add_rmsnorm(x, res_c, w, 1e-5, q_scale=qs, want_out=True)
@@ -143,4 +148,69 @@ def test_tp2_decode_step_with_fused_allreduce_norm_matches_collective():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_stack_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert all(out.get(r) for r in range(2)), dict(out)
+
+
+def _graph_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iaas_sglang_amd import ops
+    from iaas_sglang_amd.custom_all_reduce import CustomAllreduce
+    ca = CustomAllreduce(dist.group.WORLD, torch.device("cuda", 0), max_size=4 * 1024 * 1024)
+    ok = not ca.disabled
+    try:
+        g = torch.Generator().manual_seed(77)
+        for dtype, rows, H in ((torch.bfloat16, 128, 4096), (torch.float16, 16, 1024), (torch.bfloat16, 256, 8192)):
+            x = torch.zeros(rows, H, dtype=dtype, device="cuda")           # persistent graph inputs
+            res = torch.zeros(rows, H, dtype=dtype, device="cuda")
+            st = ca.staging((rows, H), dtype)
+            w = torch.randn(H, generator=g).to(dtype).cuda()
+            qs = torch.tensor([0.02], device="cuda")
+            # warm-up inside capture() but outside a stream capture only mimics the allocation (custom_all_reduce.py:476)
+            with ca.capture():
+                warm = ca.custom_all_reduce(x)
+                ok = ok and warm is not None and warm.shape == x.shape
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                dist.barrier()
+                with torch.cuda.graph(graph):
+                    y = ca.custom_all_reduce(x)                            # staged by a captured copy node
+                    st.copy_(x)                                            # "producer" writing into staging
+                    o, q = ca.all_reduce_add_rmsnorm(st, res, w, 1e-5, q_scale=qs, want_out=True)
+            ok = ok and ca.register_graph_buffers() == 0 and not ca._IS_CAPTURING
+            for it in range(3):
+                allx = (torch.randn(world, rows, H, generator=g) * 0.5).to(dtype)
+                res0 = torch.randn(rows, H, generator=g).to(dtype)
+                x.copy_(allx[rank])
+                res.copy_(res0)
+                dist.barrier()
+                graph.replay()
+                torch.cuda.synchronize()
+                want_h = allx.float().sum(0).to(dtype)                     # world 2: one rounding, any order
+                res_ref = res0.cuda()
+                want_o = ops.rmsnorm(want_h.cuda(), w, 1e-5, residual=res_ref)
+                res_ref2 = res0.cuda()
+                want_q = ops.rmsnorm_fp8(want_h.cuda(), w, 1e-5, qs, residual=res_ref2)
+                torch.cuda.synchronize()
+                good = (not ca.timed_out() and torch.equal(y.cpu(), want_h) and torch.equal(o, want_o)
+                        and torch.equal(res, res_ref) and torch.equal(q.view(torch.uint8), want_q.view(torch.uint8)))
+                if not good:
+                    print(f"[rank {rank}] FAIL graph replay {it} dtype={dtype} rows={rows} H={H} y={torch.equal(y.cpu(), want_h)} "
+                          f"o={torch.equal(o, want_o)} res={torch.equal(res, res_ref)}", flush=True)
+                ok = ok and good
+            del graph
+    finally:
+        ca.close()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_allreduce_captured_in_graph_and_replayed():
+    """`ca_comm.capture()` around a hipGraph capture (parallel_state.py:377-378) holding the plain and the fused
+    all-reduce; three replays with new inputs against the unfused eager ops."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graph_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert all(out.get(r) for r in range(2)), dict(out)

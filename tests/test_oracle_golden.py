@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import attention as oa
+from oracle import elementwise as oe
 from oracle import quant as oq
 
 FP8 = torch.float8_e4m3fn
@@ -141,3 +142,63 @@ def test_gptq_dequant_self_consistency():
     W = oq.gptq_dequantize(qweight, s, qzeros, None, gs)
     ref = (w - (z + 1).repeat_interleave(gs, 0)) * s.repeat_interleave(gs, 0)
     assert torch.equal(W, ref)
+
+
+# ---------------------------------------------------------------- tests/golden/elementwise.pt (make_golden_elementwise.py)
+RMS = ["rmsnorm_bf16_4096", "rmsnorm_fp16_1024", "rmsnorm_bf16_8192", "rmsnorm_fp16_128"]
+ROPE = ["rope_bf16_d128", "rope_fp16_d128", "rope_fp16_d64"]
+
+
+@pytest.mark.parametrize("name", RMS)
+def test_rmsnorm_oracle_matches_reference(golden_elementwise, name):
+    c = golden_elementwise[name]
+    eps = float(c["eps"])
+    # layernorm.py:128-146 (RMSNorm.forward_native), executed by the generator: bit-identical
+    assert torch.equal(oe.rmsnorm(c["x"], c["weight"], eps), c["y"])
+    y, r = oe.rmsnorm(c["x"], c["weight"], eps, c["residual"])
+    assert torch.equal(y, c["y_add"]) and torch.equal(r, c["residual_out"])
+    # the sgl-kernel tests' torch forms (test_norm.py:8-15,40-50) are the same arithmetic
+    assert torch.equal(c["y_kernel_test"], c["y"]) and torch.equal(c["y_add_kernel_test"], c["y_add"])
+    assert torch.equal(c["residual_out_kernel_test"], c["residual_out"])
+
+
+@pytest.mark.parametrize("name", ["silu_mul_bf16", "silu_mul_fp16"])
+def test_silu_and_mul_oracle_matches_reference(golden_elementwise, name):
+    c = golden_elementwise[name]
+    assert torch.equal(oe.silu_and_mul(c["x"]), c["y"])
+
+
+@pytest.mark.parametrize("name", ROPE)
+def test_rope_oracle_matches_reference(golden_elementwise, name):
+    c = golden_elementwise[name]
+    D = int(c["head_dim"])
+    cache = oe.rope_cos_sin_cache(D, int(c["max_pos"]), float(c["base"]))
+    assert torch.equal(cache, c["cos_sin_cache_f32"])           # _compute_cos_sin_cache, fp32
+    q, k = oe.rope_neox(c["positions"], c["q"].clone(), c["k"].clone(), cache, D)
+    # rotary_embedding.py:138-166 with the cache cast to the model dtype (:104-105): bit-identical
+    assert torch.equal(q, c["q_out"]) and torch.equal(k, c["k_out"])
+    # the sgl-kernel test's form rotates in fp32 and rounds once: within 2 ulp of the model dtype of the native form
+    ulp = 2 ** -8 if c["q"].dtype == torch.bfloat16 else 2 ** -11
+    torch.testing.assert_close(q.float(), c["q_out_kernel_test"].float(), atol=4 * ulp, rtol=4 * ulp)
+    torch.testing.assert_close(k.float(), c["k_out_kernel_test"].float(), atol=4 * ulp, rtol=4 * ulp)
+
+
+@pytest.mark.parametrize("name", ["merge_bf16", "merge_fp16"])
+def test_merge_state_oracle_matches_reference(golden_elementwise, name):
+    c = golden_elementwise[name]
+    o, lse = oa.merge_state(c["o_a"], c["lse_a"].clone(), c["o_b"], c["lse_b"].clone())
+    # merge_state_torch leaves its result in fp32 (bf16 * fp32 promotes); the op rounds to the I/O dtype
+    assert c["o"].dtype == torch.float32
+    assert torch.equal(o, c["o"].to(o.dtype))
+    assert torch.equal(lse, c["lse"])
+
+
+def test_weight_scale_utils_oracle_matches_reference(golden_elementwise):
+    for name in ("requantize_unfused", "requantize_fused"):
+        c = golden_elementwise[name]
+        s, w = oq.requantize_with_max_scale(c["weight"].view(FP8), c["weight_scale"], c["widths"].tolist())
+        assert torch.equal(s, c["max_scale"]) and torch.equal(w.view(torch.uint8), c["weight_out"]), name
+    c = golden_elementwise["convert_to_channelwise"]
+    assert torch.equal(oq.convert_to_channelwise(c["weight_scale"], c["widths"].tolist()), c["out"])
+    c = golden_elementwise["per_tensor_dequantize"]
+    assert torch.equal(oq.per_tensor_dequantize(c["weight"].view(FP8), c["scale"]), c["out"])
