@@ -116,6 +116,16 @@ except Exception:  # ImportError or any of SGLang's own import-time failures
     class LinearMethodBase(QuantizeMethodBase):
         """python/sglang/srt/layers/linear.py:111-149."""
 
+        @abstractmethod
+        def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int,
+                           output_partition_sizes: List[int], input_size: int, output_size: int,
+                           params_dtype: torch.dtype, **extra_weight_attrs):
+            raise NotImplementedError
+
+        @abstractmethod
+        def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+            raise NotImplementedError
+
     class UnquantizedLinearMethod(LinearMethodBase):
         """linear.py:152-193.  In a real install skipped / unquantised layers are handled by the reference's own class;
         this stand-in does the same thing -- a plain library GEMM (F.linear -> hipBLASLt), not a hot-path kernel."""
@@ -181,30 +191,166 @@ except Exception:  # ImportError or any of SGLang's own import-time failures
         @abstractmethod
         def get_scaled_act_names(self) -> List[str]: ...
 
-    class _Param(Parameter):
-        """Stand-in for layers/parameter.py classes: a Parameter that remembers the loader attributes
-        (input_dim/output_dim/packed_dim/packed_factor/weight_loader) the TP loaders read."""
+    # ---- layers/parameter.py:29-441: the parameter classes a linear method registers and the TP weight loaders of
+    # linear.py drive (`param.load_*_weight(...)`, isinstance checks on these very names).  Same names, inheritance,
+    # properties and loader signatures; the loaders are slice-and-copy only.  tests/test_interfaces_cpu.py checks them
+    # against the reference's classes, signature by signature and on reference-run vectors.
+    def _copy_exact(dst: torch.Tensor, src: torch.Tensor) -> None:
+        assert dst.shape == src.shape, f"{tuple(dst.shape)} != {tuple(src.shape)}"
+        dst.copy_(src)
 
+    class BasevLLMParameter(Parameter):
         def __new__(cls, data: torch.Tensor, **kwargs):
             return super().__new__(cls, data=data, requires_grad=False)
 
-        def __init__(self, data: torch.Tensor, weight_loader=None, input_dim=None, output_dim=None,
-                     packed_dim=None, packed_factor=None, **kwargs):
-            self.weight_loader = weight_loader
-            self.input_dim, self.output_dim = input_dim, output_dim
-            self.packed_dim, self.packed_factor = packed_dim, packed_factor
+        def __init__(self, data: torch.Tensor, weight_loader):
+            self._weight_loader = weight_loader
 
-    class ModelWeightParameter(_Param):
+        @property
+        def weight_loader(self):
+            return self._weight_loader
+
+        def _assert_and_load(self, loaded_weight: torch.Tensor):
+            _copy_exact(self.data, loaded_weight)
+
+        def load_column_parallel_weight(self, loaded_weight: torch.Tensor):
+            _copy_exact(self.data, loaded_weight)
+
+        def load_row_parallel_weight(self, loaded_weight: torch.Tensor):
+            _copy_exact(self.data, loaded_weight)
+
+        def load_merged_column_weight(self, loaded_weight: torch.Tensor, **kwargs):
+            _copy_exact(self.data, loaded_weight)
+
+        def load_qkv_weight(self, loaded_weight: torch.Tensor, **kwargs):
+            _copy_exact(self.data, loaded_weight)
+
+    class _ColumnvLLMParameter(BasevLLMParameter):
+        """Sharded along `output_dim` (column parallelism; fused qkv / gate_up shards)."""
+
+        def __init__(self, output_dim: int, **kwargs):
+            self._output_dim = output_dim
+            super().__init__(**kwargs)
+
+        @property
+        def output_dim(self):
+            return self._output_dim
+
+        def _packed_along_output(self) -> bool:
+            return isinstance(self, PackedvLLMParameter) and self.packed_dim == self.output_dim
+
+        def load_column_parallel_weight(self, loaded_weight: torch.Tensor, tp_rank: int,
+                                        use_presharded_weights: bool = False):
+            if not use_presharded_weights:
+                n = self.data.shape[self.output_dim]
+                loaded_weight = loaded_weight.narrow(self.output_dim, tp_rank * n, n)
+            _copy_exact(self.data, loaded_weight)
+
+        def load_merged_column_weight(self, loaded_weight: torch.Tensor, **kwargs):
+            offset, size = kwargs.get("shard_offset"), kwargs.get("shard_size")
+            if self._packed_along_output():
+                size, offset = self.adjust_shard_indexes_for_packing(shard_offset=offset, shard_size=size)
+            if not kwargs.get("use_presharded_weights"):
+                loaded_weight = loaded_weight.narrow(self.output_dim, kwargs.get("tp_rank") * size, size)
+            _copy_exact(self.data.narrow(self.output_dim, offset, size), loaded_weight)
+
+        def load_qkv_weight(self, loaded_weight: torch.Tensor, tp_rank: int, use_presharded_weights: bool = False,
+                            **kwargs):
+            offset, size = kwargs.get("shard_offset"), kwargs.get("shard_size")
+            if self._packed_along_output():
+                size, offset = self.adjust_shard_indexes_for_packing(shard_offset=offset, shard_size=size)
+            # q heads are split over the ranks; a kv head may be shared by `num_heads` ranks
+            shard = tp_rank if kwargs.get("shard_id") == "q" else tp_rank // kwargs.get("num_heads")
+            if not use_presharded_weights:
+                loaded_weight = loaded_weight.narrow(self.output_dim, shard * size, size)
+            _copy_exact(self.data.narrow(self.output_dim, offset, size), loaded_weight)
+
+    class RowvLLMParameter(BasevLLMParameter):
+        """Sharded along `input_dim` (row parallelism)."""
+
+        def __init__(self, input_dim: int, **kwargs):
+            self._input_dim = input_dim
+            super().__init__(**kwargs)
+
+        @property
+        def input_dim(self):
+            return self._input_dim
+
+        def load_row_parallel_weight(self, loaded_weight: torch.Tensor, tp_rank: int,
+                                     use_presharded_weights: bool = False):
+            if not use_presharded_weights:
+                n = self.data.shape[self.input_dim]
+                loaded_weight = loaded_weight.narrow(self.input_dim, tp_rank * n, n)
+            if loaded_weight.dim() == 0:
+                loaded_weight = loaded_weight.reshape(1)
+            _copy_exact(self.data, loaded_weight)
+
+    class ModelWeightParameter(_ColumnvLLMParameter, RowvLLMParameter):
         pass
 
-    class PerTensorScaleParameter(_Param):
+    class GroupQuantScaleParameter(_ColumnvLLMParameter, RowvLLMParameter):
         pass
 
-    class PackedvLLMParameter(_Param):
+    class ChannelQuantScaleParameter(_ColumnvLLMParameter):
         pass
 
-    class GroupQuantScaleParameter(_Param):
-        pass
+    class PerTensorScaleParameter(BasevLLMParameter):
+        """One scale per logical matrix of a fused module; loaders address the shard id, never the TP rank."""
 
-    class ChannelQuantScaleParameter(_Param):
-        pass
+        def __init__(self, **kwargs):
+            self.qkv_idxs = {"q": 0, "k": 1, "v": 2}
+            super().__init__(**kwargs)
+
+        def _shard_id_as_int(self, shard_id) -> int:
+            if isinstance(shard_id, int):
+                return shard_id
+            assert isinstance(shard_id, str) and shard_id in self.qkv_idxs
+            return self.qkv_idxs[shard_id]
+
+        def _load_whole(self, *args, **kwargs):
+            kwargs.pop("tp_rank", None)
+            kwargs.pop("use_presharded_weights", None)
+            BasevLLMParameter.load_row_parallel_weight(self, *args, **kwargs)
+
+        def load_row_parallel_weight(self, *args, **kwargs):
+            self._load_whole(*args, **kwargs)
+
+        def load_column_parallel_weight(self, *args, **kwargs):
+            self._load_whole(*args, **kwargs)
+
+        def load_merged_column_weight(self, *args, **kwargs):
+            self._load_into_shard_id(*args, **kwargs)
+
+        def load_qkv_weight(self, *args, **kwargs):
+            self._load_into_shard_id(*args, **kwargs)
+
+        def _load_into_shard_id(self, loaded_weight: torch.Tensor, shard_id, **kwargs):
+            if loaded_weight.dim() != 0:          # compressed-tensors scales carry a shape of [1], AutoFP8's none
+                assert loaded_weight.shape[0] == 1
+                loaded_weight = loaded_weight[0]
+            _copy_exact(self.data[self._shard_id_as_int(shard_id)], loaded_weight)
+
+    class PackedvLLMParameter(ModelWeightParameter):
+        """int4/int8 values packed `packed_factor` to a storage element along `packed_dim`."""
+
+        def __init__(self, packed_factor, packed_dim: int, marlin_tile_size: Optional[int] = None, **kwargs):
+            self._packed_factor, self._packed_dim, self._marlin_tile_size = packed_factor, packed_dim, marlin_tile_size
+            super().__init__(**kwargs)
+
+        @property
+        def packed_dim(self):
+            return self._packed_dim
+
+        @property
+        def packed_factor(self):
+            return self._packed_factor
+
+        @property
+        def marlin_tile_size(self):
+            return self._marlin_tile_size
+
+        def adjust_shard_indexes_for_packing(self, shard_size, shard_offset):
+            size, offset = shard_size // self.packed_factor, shard_offset // self.packed_factor
+            if self.marlin_tile_size is not None:
+                return size * self.marlin_tile_size, offset * self.marlin_tile_size
+            return size, offset

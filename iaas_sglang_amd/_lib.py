@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_hotpath.so")
 
+ABI_VERSION = 6          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
 MI_BF16, MI_FP16, MI_F32 = 0, 1, 2
 MI_SCALE_TENSOR, MI_SCALE_ROW = 0, 1
 MI_W4_AWQ, MI_W4_GPTQ = 0, 1
@@ -28,6 +29,9 @@ SIGNATURES = {
     "mi_kv_write_fp8": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _int, _p]),
     "mi_alloc_extend": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "mi_alloc_decode": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "mi_write_req_to_token": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "mi_get_last_loc": (_int, [_p, _i64, _p, _p, _p, _i64, _p]),
+    "mi_compute_position": (_int, [_p, _p, _int, _p, _p, _i64, _p]),
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
@@ -96,8 +100,8 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name} (ABI mismatch with include/mi_hotpath.h)")
         fn.restype = res
         fn.argtypes = args
-    if lib.mi_abi_version() != 5:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != 5")
+    if lib.mi_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.mi_abi_version()} != {ABI_VERSION}")
     return lib
 
 

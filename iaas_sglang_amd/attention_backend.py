@@ -371,6 +371,13 @@ class MiAttnBackend(AttentionBackend):
         quantization/kv_cache.py:17-82); 1.0 when the checkpoint has none (plain cast, as Triton stores it)."""
         ks = getattr(layer, "k_scale_float", None)
         vs = getattr(layer, "v_scale_float", None)
+        # a scales file (--quantization-param-path -> load_kv_cache_scales, llama.py:359-378) sets the plain
+        # k_scale / v_scale attributes and leaves the *_float ones unset
+        # (python floats; a device Parameter is never read here -- that would synchronise inside a capture)
+        if ks is None and isinstance(getattr(layer, "k_scale", None), (int, float)) and layer.k_scale > 0:
+            ks = float(layer.k_scale)
+        if vs is None and isinstance(getattr(layer, "v_scale", None), (int, float)) and layer.v_scale > 0:
+            vs = float(layer.v_scale)
         return (1.0 if ks is None else float(ks)), (1.0 if vs is None else float(vs))
 
     def _save_kv(self, forward_batch, layer, k, v):

@@ -336,3 +336,106 @@ extern "C" int mi_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc,
   MI_CHECK_LAUNCH();
   return MI_OK;
 }
+
+// ---------------------------------------------------------------- scheduler-side request bookkeeping ("K10")
+// Replace the Triton helpers the scheduler runs once per batch:
+//   write_req_to_token_pool_triton  python/sglang/srt/managers/schedule_batch.py:1848-1882
+//   get_last_loc_kernel             python/sglang/srt/managers/schedule_batch.py:1912-1932
+//   compute_position_kernel         python/sglang/srt/model_executor/forward_batch_info.py:704-732
+// Integer, bit-exact, latency-bound.  One workgroup per request; the request's offset into the flat per-token arrays
+// (the exclusive prefix sum of the extend lengths) is a coalesced 256-thread reduction over the requests before it,
+// where the Triton programs each walk them serially.
+template <typename L>
+__device__ __forceinline__ int64_t block_prefix_sum(const L* __restrict__ lens, int64_t n, int64_t* red) {
+  int64_t acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += (int64_t)lens[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  int64_t total = 0;
+  for (unsigned w = 0; w < blockDim.x / 64; ++w) total += red[w];
+  return total;
+}
+
+__global__ __launch_bounds__(256) void write_req_to_token_kernel(int32_t* __restrict__ req_to_token, int64_t stride,
+                                                                 const int64_t* __restrict__ req_pool_indices,
+                                                                 const int64_t* __restrict__ pre_lens,
+                                                                 const int64_t* __restrict__ seq_lens,
+                                                                 const int64_t* __restrict__ extend_lens,
+                                                                 const int64_t* __restrict__ out_cache_loc) {
+  __shared__ int64_t red[4];
+  const int64_t b = blockIdx.x;
+  const int64_t start = block_prefix_sum(extend_lens, b, red);
+  const int64_t pre = pre_lens[b], n = seq_lens[b] - pre;
+  int32_t* dst = req_to_token + req_pool_indices[b] * stride + pre;
+  const int64_t* src = out_cache_loc + start;
+  for (int64_t j = threadIdx.x; j < n; j += 256) dst[j] = (int32_t)src[j];
+}
+
+extern "C" int mi_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_stride,
+                                     const int64_t* req_pool_indices, const int64_t* pre_lens,
+                                     const int64_t* seq_lens, const int64_t* extend_lens,
+                                     const int64_t* out_cache_loc, int64_t batch, void* stream) {
+  MI_CHECK_ARG(batch >= 0 && batch <= 0x7fffffff);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(req_to_token && req_pool_indices && pre_lens && seq_lens && extend_lens && out_cache_loc);
+  MI_CHECK_ARG(req_to_token_stride > 0);
+  write_req_to_token_kernel<<<(unsigned)batch, 256, 0, (hipStream_t)stream>>>(
+      req_to_token, req_to_token_stride, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void get_last_loc_kernel(const int32_t* __restrict__ req_to_token, int64_t stride,
+                                                           const int64_t* __restrict__ req_pool_indices,
+                                                           const int64_t* __restrict__ prefix_lens,
+                                                           int64_t* __restrict__ result, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pre = prefix_lens[i];
+  result[i] = pre > 0 ? (int64_t)req_to_token[req_pool_indices[i] * stride + pre - 1] : -1;
+}
+
+extern "C" int mi_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
+                               const int64_t* req_pool_indices, const int64_t* prefix_lens, int64_t* result,
+                               int64_t batch, void* stream) {
+  MI_CHECK_ARG(batch >= 0);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(req_to_token && req_pool_indices && prefix_lens && result && req_to_token_stride > 0);
+  get_last_loc_kernel<<<(unsigned)cdiv64(batch, 256), 256, 0, (hipStream_t)stream>>>(
+      req_to_token, req_to_token_stride, req_pool_indices, prefix_lens, result, batch);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+template <typename L>
+__global__ __launch_bounds__(256) void compute_position_kernel(const L* __restrict__ extend_prefix_lens,
+                                                               const L* __restrict__ extend_seq_lens,
+                                                               int64_t* __restrict__ positions,
+                                                               int32_t* __restrict__ extend_start_loc) {
+  __shared__ int64_t red[4];
+  const int64_t b = blockIdx.x;
+  const int64_t start = block_prefix_sum(extend_seq_lens, b, red);
+  const int64_t pre = extend_prefix_lens ? (int64_t)extend_prefix_lens[b] : 0;
+  const int64_t n = (int64_t)extend_seq_lens[b];
+  for (int64_t j = threadIdx.x; j < n; j += 256) positions[start + j] = pre + j;
+  if (threadIdx.x == 0) extend_start_loc[b] = (int32_t)start;
+}
+
+extern "C" int mi_compute_position(const void* extend_prefix_lens /* nullable: no prefixes */,
+                                   const void* extend_seq_lens, int lens_is_i64, int64_t* positions,
+                                   int32_t* extend_start_loc, int64_t batch, void* stream) {
+  MI_CHECK_ARG(batch >= 0 && batch <= 0x7fffffff);
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(extend_seq_lens && positions && extend_start_loc);
+  hipStream_t s = (hipStream_t)stream;
+  if (lens_is_i64)
+    compute_position_kernel<int64_t><<<(unsigned)batch, 256, 0, s>>>(
+        (const int64_t*)extend_prefix_lens, (const int64_t*)extend_seq_lens, positions, extend_start_loc);
+  else
+    compute_position_kernel<int32_t><<<(unsigned)batch, 256, 0, s>>>(
+        (const int32_t*)extend_prefix_lens, (const int32_t*)extend_seq_lens, positions, extend_start_loc);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}

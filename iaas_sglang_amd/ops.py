@@ -123,6 +123,47 @@ def alloc_decode(seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: tor
                               _ptr(scratch), bs, int(page_size), _stream()), "mi_alloc_decode")
 
 
+def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, pre_lens: torch.Tensor,
+                       seq_lens: torch.Tensor, extend_lens: torch.Tensor, out_cache_loc: torch.Tensor) -> None:
+    """req_to_token[req_pool_indices[i], pre_lens[i]:seq_lens[i]] = the request's slice of out_cache_loc
+    (write_req_to_token_pool_triton, schedule_batch.py:1848-1882)."""
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    for t in (req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc):
+        assert t.dtype == torch.int64 and t.is_contiguous() and t.is_cuda
+    bs = req_pool_indices.shape[0]
+    assert pre_lens.numel() == bs and seq_lens.numel() == bs and extend_lens.numel() == bs
+    check(lib.mi_write_req_to_token(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _ptr(pre_lens),
+                                    _ptr(seq_lens), _ptr(extend_lens), _ptr(out_cache_loc), bs, _stream()),
+          "mi_write_req_to_token")
+
+
+def get_last_loc(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, prefix_lens: torch.Tensor) -> torch.Tensor:
+    """Slot of the last cached token of every request, -1 without a prefix (get_last_loc, schedule_batch.py:1885-1956)."""
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and prefix_lens.dtype == torch.int64
+    assert req_pool_indices.is_contiguous() and prefix_lens.is_contiguous()
+    out = torch.empty_like(prefix_lens)
+    check(lib.mi_get_last_loc(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _ptr(prefix_lens),
+                              _ptr(out), prefix_lens.shape[0], _stream()), "mi_get_last_loc")
+    return out
+
+
+def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor, extend_seq_lens_sum: int):
+    """(positions int64 [sum], extend_start_loc int32 [bs]) of an extend batch
+    (compute_position_triton, forward_batch_info.py:678-732; an empty extend_prefix_lens means no prefixes)."""
+    bs = extend_seq_lens.shape[0]
+    assert extend_seq_lens.dtype in (torch.int32, torch.int64) and extend_seq_lens.is_contiguous()
+    has_prefix = extend_prefix_lens.shape[0] == bs
+    if has_prefix:
+        assert extend_prefix_lens.dtype == extend_seq_lens.dtype and extend_prefix_lens.is_contiguous()
+    positions = torch.empty(int(extend_seq_lens_sum), dtype=torch.int64, device=extend_seq_lens.device)
+    start_loc = torch.empty(bs, dtype=torch.int32, device=extend_seq_lens.device)
+    check(lib.mi_compute_position(_ptr(extend_prefix_lens) if has_prefix else None, _ptr(extend_seq_lens),
+                                  int(extend_seq_lens.dtype == torch.int64), _ptr(positions), _ptr(start_loc), bs,
+                                  _stream()), "mi_compute_position")
+    return positions, start_loc
+
+
 # --------------------------------------------------------------------- attention
 def decode_workspace_numel(batch: int, num_q_heads: int, v_head_dim: int, num_splits: int) -> int:
     return lib.mi_decode_attn_workspace_bytes(batch, num_q_heads, v_head_dim, num_splits) // 4

@@ -6,10 +6,12 @@ from .awq import AWQConfig, AWQLinearMethod
 from .compressed_tensors import CompressedTensorsConfig, CompressedTensorsLinearMethod, CompressedTensorsW8A8Fp8
 from .fp8 import Fp8Config, Fp8LinearMethod, apply_fp8_linear
 from .gptq import GPTQConfig, GPTQLinearMethod
+from .kv_cache import BaseKVCacheMethod, Fp8KVCacheMethod, kv_cache_scales_loader, load_kv_cache_scales
 
 MI_QUANTIZATION_METHODS = {"fp8": Fp8Config, "awq": AWQConfig, "gptq": GPTQConfig,
                            "compressed-tensors": CompressedTensorsConfig}
 
 __all__ = ["Fp8Config", "Fp8LinearMethod", "apply_fp8_linear", "AWQConfig", "AWQLinearMethod",
            "GPTQConfig", "GPTQLinearMethod", "CompressedTensorsConfig", "CompressedTensorsLinearMethod",
-           "CompressedTensorsW8A8Fp8", "MI_QUANTIZATION_METHODS"]
+           "CompressedTensorsW8A8Fp8", "BaseKVCacheMethod", "Fp8KVCacheMethod", "kv_cache_scales_loader",
+           "load_kv_cache_scales", "MI_QUANTIZATION_METHODS"]

@@ -71,7 +71,10 @@ class Fp8Config(QuantizationConfig):
             if _is_layer_skipped(prefix, self.ignored_layers):
                 return UnquantizedLinearMethod()
             return Fp8LinearMethod(self)
-        return None  # MoE / attention-layer hooks: not on this path
+        if hasattr(layer, "tp_k_head_num") and hasattr(layer, "k_scale"):     # RadixAttention (fp8.py:210-211)
+            from .kv_cache import Fp8KVCacheMethod
+            return Fp8KVCacheMethod(self)
+        return None  # MoE hooks: not on this path
 
     def get_scaled_act_names(self) -> List[str]:
         return []

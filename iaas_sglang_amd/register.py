@@ -7,7 +7,10 @@ registration wraps those seams without editing any reference file (SURVEY sectio
 
   1. ModelRunner._get_attention_backend  -> returns MiAttnBackend for --attention-backend mi355x
   2. ServerArgs argparse choices          -> accepts the new backend name
-  3. srt.utils.support_triton             -> False for our name (scheduler helpers use torch forms)
+  3. the scheduler-side Triton helpers    -> our HIP kernels under the names the scheduler calls:
+       schedule_batch.write_req_to_token_pool_triton[(bs,)](...), schedule_batch.get_last_loc_triton,
+       forward_batch_info.compute_position_triton  (support_triton() stays True for our backend name, so the
+       scheduler takes its one-launch branch instead of the per-request python loop, schedule_batch.py:1290-1309)
   4. QUANTIZATION_METHODS["fp8"|"awq"|"gptq"] -> our configs; awq/gptq are moved out of the
      vllm-gated table (quantization/__init__.py:75-120)
 
@@ -30,7 +33,6 @@ def register(override_quantization: bool = True) -> bool:
     try:
         import sglang.srt.model_executor.model_runner as mr
         import sglang.srt.server_args as sargs
-        import sglang.srt.utils as sutils
     except Exception:
         return False
 
@@ -58,20 +60,8 @@ def register(override_quantization: bool = True) -> bool:
 
     sargs.ServerArgs.add_cli_args = staticmethod(add_cli_args)
 
-    # 3. scheduler-side triton helpers off for our backend
-    orig_support = sutils.support_triton
-
-    def support_triton(backend: str) -> bool:
-        return False if backend == BACKEND_NAME else orig_support(backend)
-
-    sutils.support_triton = support_triton
-    for modname in ("sglang.srt.managers.schedule_batch", "sglang.srt.model_executor.forward_batch_info"):
-        try:
-            mod = __import__(modname, fromlist=["support_triton"])
-            if hasattr(mod, "support_triton"):
-                mod.support_triton = support_triton
-        except Exception:
-            pass
+    # 3. scheduler-side helpers: same names, same call forms, HIP kernels behind them
+    install_scheduler_helpers()
 
     # 4. quantization registry
     if override_quantization:
@@ -83,4 +73,48 @@ def register(override_quantization: bool = True) -> bool:
             q.BASE_QUANTIZATION_METHODS[name] = cfg
             q.VLLM_QUANTIZATION_METHODS.pop(name, None)
     _registered = True
+    return True
+
+
+class _GridLaunch:
+    """`kernel[grid](*args)` call form of a Triton launch for a plain host function (the grid is implied)."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __getitem__(self, grid):
+        return self._fn
+
+
+def write_req_to_token_pool(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc,
+                            req_to_token_ptr_stride=None):
+    """Argument list of write_req_to_token_pool_triton (schedule_batch.py:1848-1857)."""
+    from . import ops
+    ops.write_req_to_token(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc)
+
+
+def get_last_loc(req_to_token, req_pool_indices_tensor, prefix_lens_tensor):
+    """get_last_loc_triton (schedule_batch.py:1935-1956)."""
+    from . import ops
+    return ops.get_last_loc(req_to_token, req_pool_indices_tensor, prefix_lens_tensor)
+
+
+def compute_position(extend_prefix_lens, extend_seq_lens, extend_seq_lens_sum):
+    """compute_position_triton (forward_batch_info.py:678-701)."""
+    from . import ops
+    return ops.compute_position(extend_prefix_lens, extend_seq_lens, extend_seq_lens_sum)
+
+
+def install_scheduler_helpers(schedule_batch=None, forward_batch_info=None) -> bool:
+    """Bind the three helpers into the scheduler's modules (given, or imported from an installed SGLang)."""
+    try:
+        if schedule_batch is None:
+            import sglang.srt.managers.schedule_batch as schedule_batch
+        if forward_batch_info is None:
+            import sglang.srt.model_executor.forward_batch_info as forward_batch_info
+    except Exception:
+        return False
+    schedule_batch.write_req_to_token_pool_triton = _GridLaunch(write_req_to_token_pool)
+    schedule_batch.get_last_loc_triton = get_last_loc
+    forward_batch_info.compute_position_triton = compute_position
     return True

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
@@ -86,6 +86,25 @@ int mi_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const i
 int mi_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
                     int64_t* out_indices, int64_t* ret_value, int64_t* scratch, int64_t batch,
                     int64_t page_size, void* stream);
+
+/* Scheduler-side request bookkeeping of an EXTEND batch (one launch each, integer, bit-exact).
+ *  mi_write_req_to_token: req_to_token[req_pool_indices[i], pre_lens[i] : seq_lens[i]] =
+ *      out_cache_loc[sum_{j<i} extend_lens[j] ...]  (int64 slot ids stored as int32).
+ *      replaces: write_req_to_token_pool_triton, managers/schedule_batch.py:1848-1882 (call site :1290-1301; the
+ *      python fallback loop :1303-1309 is what an unmodified scheduler runs for a non-Triton backend)
+ *  mi_get_last_loc: result[i] = prefix_lens[i] > 0 ? req_to_token[req_pool_indices[i], prefix_lens[i] - 1] : -1
+ *      replaces: get_last_loc_triton / get_last_loc_torch, managers/schedule_batch.py:1885-1956
+ *  mi_compute_position: positions[start_i + j] = prefix_i + j (j < extend_i), extend_start_loc[i] = start_i =
+ *      sum_{j<i} extend_j; extend_prefix_lens == NULL means no prefixes.  lens int32 (as ForwardBatch.init_new
+ *      builds them) or int64.
+ *      replaces: compute_position_triton / compute_position_torch, model_executor/forward_batch_info.py:678-750 */
+int mi_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                          const int64_t* pre_lens, const int64_t* seq_lens, const int64_t* extend_lens,
+                          const int64_t* out_cache_loc, int64_t batch, void* stream);
+int mi_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                    const int64_t* prefix_lens, int64_t* result, int64_t batch, void* stream);
+int mi_compute_position(const void* extend_prefix_lens, const void* extend_seq_lens, int lens_is_i64,
+                        int64_t* positions, int32_t* extend_start_loc, int64_t batch, void* stream);
 
 /* ------------------------------------------------------------------- attention */
 

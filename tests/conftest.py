@@ -28,3 +28,9 @@ def golden_quant():
 def golden_elementwise():
     import torch
     return torch.load(os.path.join(ROOT, "tests", "golden", "elementwise.pt"), weights_only=True)
+
+
+@pytest.fixture(scope="session")
+def golden_sched():
+    import torch
+    return torch.load(os.path.join(ROOT, "tests", "golden", "sched.pt"), weights_only=True)

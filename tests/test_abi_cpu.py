@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f"{n} declared in mi_hotpath.h but not exported"
         assert n in L.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
     assert set(L.SIGNATURES) == set(names)
-    assert L.lib.mi_abi_version() == 5
+    hdr = open(os.path.join(ROOT, "include", "mi_hotpath.h")).read()
+    assert L.lib.mi_abi_version() == int(re.search(r"#define MI_ABI_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
 
 
 def test_product_never_imports_oracle():

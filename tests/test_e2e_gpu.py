@@ -46,7 +46,7 @@ def _oracle_forward(stack_w, shape, hidden, positions, kc, vc, r2t, rpi, seq_len
 
 
 @pytest.mark.parametrize("scheme", ["dynamic", "static"])
-@pytest.mark.parametrize("weight_range,tol", [(1e-3, 1e-3), (0.05, 5e-2)])
+@pytest.mark.parametrize("weight_range,tol", [(1e-3, 1e-3), (0.05, None)])
 def test_tiny_llama_fp8_extend_then_decode(weight_range, tol, scheme):
     from iaas_sglang_amd import harness as H
     from iaas_sglang_amd.attention_backend import MiAttnBackend
@@ -84,11 +84,19 @@ def test_tiny_llama_fp8_extend_then_decode(weight_range, tol, scheme):
     ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc, r2t, fb.req_pool_indices.cpu(),
                           fb.seq_lens.cpu(), fb.extend_prefix_lens.cpu(), fb.extend_seq_lens.cpu(),
                           fb.out_cache_loc.cpu(), decode=False)
-    assert float((logits.float().cpu() - ref).abs().max()) < tol
+    # +-1e-3 dummy weights: the north-star bar, max-abs < 1e-3.  Weights of +-0.05 give logits of order 0.5: HIP and
+    # oracle share the quantised weights and differ by accumulation order and one rounding per op, plus the odd fp8
+    # activation code that flips on such a difference -- bounded relative to the logits: 2 % of max |logit|
+    def bound(r):
+        return tol if tol is not None else 0.02 * float(r.abs().max())
+    err = float((logits.float().cpu() - ref).abs().max())
+    print(f"e2e extend: max|logit|={float(ref.abs().max()):.4f} err={err:.3e} bound={bound(ref):.3e}")
+    assert err < bound(ref)
+    tol_kv = tol if tol is not None else 5e-2
     # the KV pool after prefill is what the oracle wrote (bf16 rounding of slightly different fp8 sums aside)
     for li in range(shape.layers):
         torch.testing.assert_close(runner.token_to_kv_pool.k_buffer[li].cpu().float(), kc[li].float(),
-                                   atol=tol, rtol=2e-2)
+                                   atol=tol_kv, rtol=2e-2)
     # two decode steps on top (seq_lens grow by one, new slot per request)
     lens = [p + e for p, e in zip(prefix, extend)]
     next_slot = sum(lens) + 1
@@ -110,7 +118,9 @@ def test_tiny_llama_fp8_extend_then_decode(weight_range, tol, scheme):
         ref = _oracle_forward(W, shape, hidden, fb.positions.cpu(), kc, vc,
                               runner.req_to_token_pool.req_to_token.cpu(), fb.req_pool_indices.cpu(),
                               fb.seq_lens.cpu(), None, None, loc, decode=True)
-        assert float((logits.float().cpu() - ref).abs().max()) < tol
+        err = float((logits.float().cpu() - ref).abs().max())
+        print(f"e2e decode {step}: max|logit|={float(ref.abs().max()):.4f} err={err:.3e} bound={bound(ref):.3e}")
+        assert err < bound(ref)
 
 
 @pytest.mark.parametrize("ctx,trials", [

@@ -183,3 +183,68 @@ def test_compressed_tensors_fp8_scheme_selection_and_weights():
         CompressedTensorsConfig.from_config(_ct_config(wtype="int")).get_quant_method(_FakeLinear(), "x.q_proj")
     with pytest.raises(NotImplementedError):          # static per-token activations: not an fp8 w8a8 form
         CompressedTensorsConfig.from_config(_ct_config(act_strategy="token")).get_quant_method(_FakeLinear(), "x.q_proj")
+
+
+# ---------------------------------------------------------------- fp8 KV-cache scales (quantization/kv_cache.py)
+def test_kv_cache_scales_loader_on_the_reference_fixture():
+    """test/srt/kv_cache_scales_llama3_8b.json (the reference's own data file, copied as a fixture): 32 layers, TP 1."""
+    import json
+    import os
+    import types
+
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import kv_cache_scales_loader, load_kv_cache_scales
+    path = os.path.join(os.path.dirname(__file__), "golden", "kv_cache_scales_llama3_8b.json")
+    raw = json.load(open(path))["kv_cache"]["scaling_factor"]["0"]
+    got = dict(kv_cache_scales_loader(path, 0, 1, 32, "llama"))
+    assert got == {int(k): v for k, v in raw.items()} and len(got) == 32 and got[0] == 0.0408
+    # every validation failure degrades to "no scales" (weight_utils.py:947-966)
+    assert list(kv_cache_scales_loader(path, 0, 2, 32, "llama")) == []          # TP size mismatch
+    assert list(kv_cache_scales_loader(path, 0, 1, 31, "llama")) == []          # layer count mismatch
+    assert list(kv_cache_scales_loader(path, 0, 1, 32, "qwen2")) == []          # model type mismatch
+    assert list(kv_cache_scales_loader(path + ".missing", 0, 1, 32, "llama")) == []
+    # llama.py:359-378: the factor becomes k_scale and v_scale of every attention layer ...
+    layers = [types.SimpleNamespace(k_scale=None, v_scale=None, k_scale_float=None, v_scale_float=None) for _ in range(32)]
+    assert load_kv_cache_scales(layers, path, 0, 1, "llama") == 32
+    assert layers[6].k_scale == layers[6].v_scale == 0.1768
+    # ... which is where the backend picks them up
+    assert MiAttnBackend._kv_scales(layers[6]) == (0.1768, 0.1768)
+    assert MiAttnBackend._kv_scales(types.SimpleNamespace()) == (1.0, 1.0)
+
+
+def test_kv_cache_method_scale_resolution():
+    """BaseKVCacheMethod.process_weights_after_loading (kv_cache.py:45-82): both / none / single scale loaded."""
+    import types
+
+    import torch
+
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import Fp8Config, Fp8KVCacheMethod
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+    attn = types.SimpleNamespace(tp_k_head_num=8, k_scale=None, v_scale=None)
+    method = cfg.get_quant_method(attn, "model.layers.0.self_attn.attn")
+    assert isinstance(method, Fp8KVCacheMethod)
+    for loaded, want in (((0.5, 0.25), (0.5, 0.25)), ((-1.0, -1.0), (1.0, 1.0)), ((0.125, -1.0), (0.125, 0.125))):
+        method.create_weights(attn)
+        assert float(attn.k_scale) == -1.0 and float(attn.v_scale) == -1.0
+        attn.k_scale.data.fill_(loaded[0])
+        attn.v_scale.data.fill_(loaded[1])
+        method.process_weights_after_loading(attn)
+        assert (attn.k_scale_float, attn.v_scale_float) == want
+        assert (float(attn.k_scale), float(attn.v_scale)) == want
+        assert MiAttnBackend._kv_scales(attn) == want
+    import pytest
+    with pytest.raises(RuntimeError):
+        method.apply(attn)
+
+
+def test_install_scheduler_helpers_binds_the_call_forms():
+    """register.install_scheduler_helpers: the names and call forms schedule_batch.py:1290-1301 / :1885-1897 and
+    forward_batch_info.py:388-393 use (no GPU: only the binding is checked)."""
+    import types
+
+    from iaas_sglang_amd import register as R
+    sb, fbi = types.ModuleType("schedule_batch"), types.ModuleType("forward_batch_info")
+    assert R.install_scheduler_helpers(sb, fbi)
+    assert sb.write_req_to_token_pool_triton[(7,)] is R.write_req_to_token_pool     # kernel[grid](...) form
+    assert sb.get_last_loc_triton is R.get_last_loc and fbi.compute_position_triton is R.compute_position

@@ -6,6 +6,7 @@ import torch
 from oracle import attention as oa
 from oracle import elementwise as oe
 from oracle import quant as oq
+from oracle import sched as osch
 
 FP8 = torch.float8_e4m3fn
 
@@ -202,3 +203,16 @@ def test_weight_scale_utils_oracle_matches_reference(golden_elementwise):
     assert torch.equal(oq.convert_to_channelwise(c["weight_scale"], c["widths"].tolist()), c["out"])
     c = golden_elementwise["per_tensor_dequantize"]
     assert torch.equal(oq.per_tensor_dequantize(c["weight"].view(FP8), c["scale"]), c["out"])
+
+
+# ---------------------------------------------------------------- tests/golden/sched.pt (make_golden_sched.py)
+@pytest.mark.parametrize("name", ["small", "one", "wide", "long"])
+def test_sched_oracle_matches_reference(golden_sched, name):
+    c = golden_sched[name]
+    assert torch.equal(osch.get_last_loc(c["req_to_token"], c["req_pool_indices"], c["prefix_lens"]), c["last_loc"])
+    r2t = osch.write_req_to_token(c["req_to_token"].clone(), c["req_pool_indices"], c["prefix_lens"], c["seq_lens"],
+                                  c["extend_lens"], c["out_cache_loc"])
+    assert torch.equal(r2t, c["req_to_token_after"])
+    pos, start = osch.compute_position(c["prefix_lens"].to(torch.int32), c["extend_lens"].to(torch.int32))
+    assert torch.equal(pos, c["positions"]) and torch.equal(start, c["extend_start_loc"])
+    assert start.dtype == c["extend_start_loc"].dtype == torch.int32

@@ -74,6 +74,7 @@ def test_fp8_gemm_golden(golden_quant, name):
 @pytest.mark.parametrize("M,N,K", [(1, 16, 512), (128, 128, 1024), (17, 200, 4096), (130, 72, 48), (128, 6144, 4096),
                                    (64, 4096, 14336), (300, 520, 1024), (512, 256, 256), (257, 1000, 512),
                                    (2048, 6144, 4096),
+                                   (128, 28672, 4096), (128, 4096, 14336),         # C3 gate_up / down at the metric's batch
                                    # C5 per rank (Llama-3-70B, TP=8, batch 256): qkv, o, gate_up, down
                                    (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584),
                                    (136, 4096, 4096), (500, 4096, 2048),           # chunks of rows: 136, 256 + 244
@@ -127,6 +128,7 @@ def _rand_awq(K, N, g, dtype, gen):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,g", [(1, 128, 256, 128), (64, 4096, 4096, 128), (19, 256, 1024, 128),
                                      (64, 12288, 4096, 128), (33, 64, 11008, 128),
+                                     (64, 22016, 4096, 128), (64, 4096, 11008, 128),      # C4 gate_up / down (Llama-2-7B, batch 64)
                                      (200, 4096, 4096, 128), (512, 1024, 1024, 128),      # 128-row chunks of the decode kernel
                                      (513, 1024, 2048, 128), (2048, 4096, 1024, 128)])    # dequantise + dense GEMM
 def test_awq_fused_gemm_vs_oracle(dtype, M, N, K, g):
@@ -239,3 +241,37 @@ def test_compressed_tensors_w8a8_fp8_linear_vs_oracle(strategy, dynamic):
     torch.testing.assert_close(y.cpu().float(), ref.float(), atol=2e-2, rtol=2 ** -6)
     if strategy == "tensor":       # the requantised weight bytes themselves are bit-exact
         assert torch.equal(lin.weight.data.t().contiguous().cpu().view(torch.uint8), w_o.view(torch.uint8))
+
+
+def test_captured_gemm_survives_scratch_growth():
+    """Graphs are captured at start-up, eager prefill comes later: a prefill GEMM that needs more split-K scratch than
+    the captured decode GEMM must not free the buffer the graph writes its slabs to (ops._gemm_workspace retires it)."""
+    o_ = ops()
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 128, 4096, 4096
+    a = torch.randn(M, K, generator=g).to(FP8).to(DEV)
+    b = torch.randn(N, K, generator=g).to(FP8).to(DEV)
+    sa, sb = torch.tensor([0.01], device=DEV), torch.tensor([0.02], device=DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    o_.fp8_gemm(a, b.t(), sa, sb, torch.bfloat16, out=out)          # warm-up sizes the scratch for this shape
+    want = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        o_.fp8_gemm(a, b.t(), sa, sb, torch.bfloat16, out=out)
+    before = o_._GEMM_WS[str(a.device)]
+    # a larger eager GEMM (tile kernel, split-K slabs) grows the scratch ...
+    big_a = torch.randn(2048, 14336, generator=g).to(FP8).to(DEV)
+    big_b = torch.randn(4096, 14336, generator=g).to(FP8).to(DEV)
+    need = o_.lib.mi_fp8_gemm_workspace_bytes(2048, 4096, 14336)
+    o_._gemm_workspace(max(need, before.numel() + 1), a.device)
+    o_.fp8_gemm(big_a, big_b.t(), sa, sb, torch.bfloat16)
+    after = o_._GEMM_WS[str(a.device)]
+    assert after.data_ptr() != before.data_ptr() and any(t is before for t in o_._GEMM_WS_RETIRED)
+    # ... and other allocations may now land anywhere: the captured graph still owns its slabs
+    junk = [torch.full((before.numel(),), 0x7f, dtype=torch.uint8, device=DEV) for _ in range(4)]
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert all(int(t.min()) == 0x7f for t in junk)
