@@ -13,6 +13,7 @@ req_to_token) are resident in HBM before the timed region.  Prints ONE JSON line
          --master-port P bench.py --gpus N --steps K --warmup W          (TP=N over RCCL)
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -33,7 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--model", choices=["llama3-8b", "llama3-70b"], default="llama3-8b",
+                    help="llama3-8b = BASELINE.json's headline (C3); llama3-70b = its TP=8 configuration (C5, batch 256)")
+    ap.add_argument("--batch", type=int, default=0, help="decode batch (default: 128 for llama3-8b, 256 for llama3-70b)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
     ap.add_argument("--contiguous", action="store_true", help="contiguous KV slots instead of scattered")
@@ -47,7 +50,10 @@ def parse():
                     "single-GPU rehearsals of the TP path with MI_BENCH_SAME_GPU=1)")
     ap.add_argument("--no-custom-ar", action="store_true", help="TP>1: use RCCL only (skip the native xGMI all-reduce)")
     ap.add_argument("--splits", type=int, default=0, help="force the split-KV count (0 = backend heuristic)")
-    ap.add_argument("--prefill-batch", type=int, default=8, help="sequences of --seq tokens in the prefill leg (0 = skip)")
+    ap.add_argument("--prefill-batch", type=int, default=-1,
+                    help="sequences of --seq tokens in the prefill leg (-1 = the decode batch: the metric's 128 x 2048; 0 = skip)")
+    ap.add_argument("--prefill-chunk", type=int, default=16, help="sequences per EXTEND batch of the prefill leg")
+    ap.add_argument("--no-plugin-surface", action="store_true", help="skip the unfused plugin-surface-only step timing")
     ap.add_argument("--kv-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="KV cache dtype: bf16 is BASELINE.json's configuration (the headline); fp8 = e4m3fn pool "
                          "(SURVEY 8f row 1), reported as a variant -- a different workload, not the headline")
@@ -217,31 +223,56 @@ def ragged_attention_leg(H, stack, runner, backend, B, S, dev, reps=2):
             "work_items": None if md.work is None else int(md.work.shape[0])}
 
 
-def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, reps=2):
-    """Prefill TFLOP/s (the other half of BASELINE.json's metric) on a bounded sample: one EXTEND batch
-    of `nseq` sequences x S new tokens (no cached prefix), whole layer stack, eager launches."""
-    fb = H.make_extend_batch(runner, backend, [0] * nseq, [S] * nseq, dev, seed=3)
-    T = nseq * S
-    hidden = torch.randn(T, shape.hidden, device=dev, dtype=torch.float32).to(stack.dtype)
+MFMA_PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak
 
-    def run():
+
+def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, chunk=16):
+    """Prefill TFLOP/s, the other half of BASELINE.json's metric, at the metric's size: `nseq` sequences x S new
+    tokens (no cached prefix) through the whole layer stack, as ceil(nseq / chunk) EXTEND batches of `chunk`
+    sequences each (what a scheduler with a 32k-token prefill budget would issue), eager launches, every chunk
+    writing its K/V rows to scattered pool slots.  One untimed chunk first (lazy inits, scratch growth); the timed region covers ALL
+    chunks between two barrier + synchronize pairs."""
+    chunks = []
+    done = 0
+    while done < nseq:
+        n = min(chunk, nseq - done)
+        chunks.append(n)
+        done += n
+
+    def run(n, seed):
+        fb = H.make_extend_batch(runner, backend, [0] * n, [S] * n, dev, seed=seed)
+        hidden = torch.randn(n * S, shape.hidden, device=dev, dtype=torch.float32).to(stack.dtype)
+        return fb, hidden
+
+    def forward(fb, hidden):
         backend.init_forward_metadata(fb)
         return stack.forward(hidden, fb.positions, fb, backend, last_token_logits=fb.extend_seq_lens)
 
-    run()
+    batches = {n: run(n, 3 + n) for n in sorted(set(chunks))}
+    forward(*batches[chunks[0]])
     barrier_sync(world)
     t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
+    for n in chunks:
+        forward(*batches[n])
     barrier_sync(world)
-    sec = (time.perf_counter() - t0) / reps
+    sec = time.perf_counter() - t0
+    T = nseq * S
     lin = 2.0 * T * shape.layers * ((shape.num_heads + 2 * shape.num_kv_heads) * shape.head_dim * shape.hidden
                                     + shape.num_heads * shape.head_dim * shape.hidden + 3 * shape.intermediate * shape.hidden)
     attn = 4.0 * shape.num_heads * shape.head_dim * nseq * (S * (S + 1) / 2) * shape.layers     # causal QK^T + PV
     head = 2.0 * nseq * shape.vocab * shape.hidden
     flops = lin + attn + head
+    # MFMA roofline of the leg: fp8 linears at the dense fp8 peak, attention and the bf16 lm_head at the bf16 peak
+    ideal = (lin / MFMA_PEAK_FP8_TFLOPS + (attn + head) / MFMA_PEAK_BF16_TFLOPS) / 1e12 / world
     return {"tflops": round(flops / sec / 1e12, 2), "ms": round(sec * 1e3, 2), "tokens": T,
-            "sample": f"{nseq} sequences x {S} tokens, no prefix, {shape.layers} layers, eager; "
+            "tokens_per_s": round(T / sec, 1),
+            "roofline": {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2),
+                         "peak": round(flops / ideal / 1e12, 1), "unit": "TFLOP/s",
+                         "frac": round(ideal / sec, 4),
+                         "note": "peak = flops / (fp8 linear flops at 5 PF + bf16 attention and lm_head flops at 2.5 PF per GPU)"},
+            "sample": f"{nseq} sequences x {S} tokens = the metric's batch, no prefix, {shape.layers} layers, eager, "
+                      f"{len(chunks)} EXTEND batches of {chunk} sequences; "
                       f"flops = linears {lin:.3e} + causal attention {attn:.3e} + lm_head {head:.3e}"}
 
 
@@ -331,7 +362,11 @@ def main():
     from iaas_sglang_amd.quantization import Fp8Config
     import dataclasses
 
-    shape = H.LLAMA3_8B
+    shape = {"llama3-8b": H.LLAMA3_8B, "llama3-70b": H.LLAMA3_70B}[a.model]
+    if not a.batch:
+        a.batch = 128 if a.model == "llama3-8b" else 256
+    if a.prefill_batch < 0:
+        a.prefill_batch = a.batch
     if a.layers:
         shape = dataclasses.replace(shape, layers=a.layers)
     tp, B, S, dtype = world, a.batch, a.seq, torch.bfloat16
@@ -363,24 +398,31 @@ def main():
         logits = stack.forward(hidden, fb.positions, fb, backend)
         torch.argmax(logits, dim=-1, out=out_ids)
 
-    step()                      # eager once: allocator warm-up, lazy inits
-    barrier_sync(world)
-    graph = None
-    if not a.no_graph and (world == 1 or a.dist_backend == "nccl"):   # gloo collectives cannot be captured
+    def capture(fn):
+        """hipGraph of one step (None when capture is impossible, e.g. gloo collectives): eager once on a side stream
+        (allocator warm-up, lazy inits), then the capture."""
+        fn()
+        barrier_sync(world)
+        if a.no_graph or not (world == 1 or a.dist_backend == "nccl"):
+            return None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                step()
+                fn()
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
+            g = torch.cuda.CUDAGraph()
+            with (custom_ar.capture() if custom_ar is not None else contextlib.nullcontext()):
+                with torch.cuda.graph(g):
+                    fn()
+            return g
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            graph = None
             torch.cuda.synchronize()
+            return None
+
+    graph = capture(step)
     run = graph.replay if graph is not None else step
 
     for _ in range(a.warmup):
@@ -395,6 +437,47 @@ def main():
     elapsed = max_over_ranks(elapsed, world, dev)
     ms_per_step = elapsed / a.steps * 1e3
     tokens_per_s = B / (ms_per_step * 1e-3)          # TP: one batch of B tokens per step for the whole job
+
+    def synced_median(fn, n):
+        """bench_one_batch.latency_test_run_once (bench_one_batch.py:332-430): every decode step bracketed by a device
+        synchronisation, the median latency reported."""
+        lat = []
+        for _ in range(n):
+            barrier_sync(world)
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t)
+        return max_over_ranks(sorted(lat)[len(lat) // 2], world, dev) * 1e3
+
+    median_ms = synced_median(run, max(5, a.steps))
+
+    # ---- the same step through the plugin surfaces ONLY, as an unmodified model file would drive them
+    # (models/llama.py:245-268: norm -> qkv_proj.apply -> rope -> attn.forward -> o_proj.apply -> norm -> gate_up.apply
+    # -> act -> down.apply): no fused linear+consumer entry points, no producer-side fp8 quantisation
+    plugin_only = None
+    if not a.no_plugin_surface:
+        try:
+            H.LlamaStack.fuse_decode_layer, H.Linear.fuse_producer_quant = False, False
+            g2 = capture(step)
+            run2 = g2.replay if g2 is not None else step
+            for _ in range(a.warmup):
+                run2()
+            barrier_sync(world)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                run2()
+            barrier_sync(world)
+            ms2 = max_over_ranks(time.perf_counter() - t1, world, dev) / a.steps * 1e3
+            plugin_only = {"ms_per_step": round(ms2, 4), "tokens_per_s": round(B / (ms2 * 1e-3), 1),
+                           "median_synced_ms": round(synced_median(run2, max(5, a.steps)), 4), "hipgraph": g2 is not None,
+                           "what": "apply()/forward() per layer exactly as models/llama.py:245-268 calls them; the "
+                                   "headline additionally uses the fused linear+consumer entry points of DESIGN 3.6"}
+            del g2
+        except Exception as e:  # informational: never lose the headline to it
+            plugin_only = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            H.LlamaStack.fuse_decode_layer, H.Linear.fuse_producer_quant = True, True
 
     # ---- roofline of the dominant kernel (decode attention), measured live with HIP events
     Hq, Hkv, D = stack.Hq, stack.Hkv, shape.head_dim
@@ -416,7 +499,7 @@ def main():
     prefill = None
     if a.prefill_batch > 0:
         try:
-            prefill = prefill_leg(H, stack, runner, backend, shape, a.prefill_batch, S, dev, world)
+            prefill = prefill_leg(H, stack, runner, backend, shape, a.prefill_batch, S, dev, world, chunk=a.prefill_chunk)
         except Exception as e:   # the decode number must not be lost to a prefill-side problem
             prefill = {"error": f"{type(e).__name__}: {e}"}
     ragged = None
@@ -427,10 +510,12 @@ def main():
             ragged = {"error": f"{type(e).__name__}: {e}"}
     result = {
         "metric": "decode tokens/s (Llama-3-8B FP8, batch 128, KV seq 2048)" + (" [variant: fp8 KV cache]" if kv8 else "")
-                  + ("" if (B, S, a.layers) == (128, 2048, 0) else
-                     f" [variant: batch {B}, KV seq {S}" + (f", {a.layers} layers" if a.layers else "") + "]"),
+                  + ("" if (a.model, B, S, a.layers) == ("llama3-8b", 128, 2048, 0) else
+                     f" [variant: {shape.name}, batch {B}, KV seq {S}" + (f", {a.layers} layers" if a.layers else "") + "]"),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "median_synced_ms": round(median_ms, 4), "tokens_per_s_median_synced": round(B / (median_ms * 1e-3), 1),
+        "plugin_surface_only": plugin_only,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), " + ("fp8 e4m3" if kv8 else "bf16") + " KV/f32 softmax (attention)",
         "data": "synthetic",
         "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears ({a.act_scheme} activation scale), "
@@ -449,7 +534,7 @@ def main():
                      "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(t_attn * 1e6, 2)},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(H.LLAMA3_8B, B, S)
+        result["cpu_baseline"] = cpu_baseline({"llama3-8b": H.LLAMA3_8B, "llama3-70b": H.LLAMA3_70B}[a.model], B, S)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

@@ -142,7 +142,7 @@ def test_requantize_with_max_scale_golden(golden_elementwise, name):
     cfg = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="dynamic")
 
     class FakeLinear(torch.nn.Module):
-        pass
+        output_partition_sizes = widths
     lin = FakeLinear()
     method = cfg.get_quant_method(lin, "model.layers.0.self_attn.qkv_proj")
     K = c["weight"].shape[1]
