@@ -103,3 +103,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_byte_addr_
                : "v"(gsrc), "s"(dst)
                : "memory");
 }
+
+// a wave-uniform pointer forced into SGPRs (values derived through integer division live in VGPRs even when uniform,
+// and an "s" asm operand does not move them)
+__device__ __forceinline__ const uint8_t* uniform_ptr(const void* ptr) {
+  const uint64_t v = (uint64_t)(uintptr_t)ptr;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// LDS-DMA, scalar base + 32-bit lane offset; lds_dst wave-uniform (already an SGPR value)
+__device__ __forceinline__ void glds16_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+// the 4-byte form: 256 B per wave instruction, lane L -> LDS byte lds_dst + 4 L
+__device__ __forceinline__ void glds4_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}

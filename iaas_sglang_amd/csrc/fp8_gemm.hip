@@ -537,14 +537,6 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
 }
 
 
-// LDS-DMA, scalar base + 32-bit lane offset; lds_dst wave-uniform (already an SGPR value)
-__device__ __forceinline__ void glds16_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(lane_off), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
 
 // ---------------------------------------------------------------------------------------------
 // fp8_gemm_xd_kernel: the decode-shaped GEMM with a DEEP ring of 128-byte k-phases.

@@ -121,17 +121,21 @@ template <> struct Deq<f16_t> {
     return __builtin_bit_cast(f16x8, u32x4{o[0], o[1], o[2], o[3]});
   }
 };
+template <int I> __device__ __forceinline__ float ub(uint32_t v) { return (float)((v >> (8 * I)) & 0xffu); }   // v_cvt_f32_ubyteI
 template <> struct Deq<bf16_t> {
+  // (e - z) * s with e, z small integers and s a bf16: e*s and z*s are exact in fp32 (4 + 8 significant bits) and
+  // so is their difference, so ONE fma per element gives the exact product and v_cvt_pk_bf16_f32 rounds it once --
+  // the bits of round_bf16((float)(e - z) * s).  Bytes instead of nibbles feed v_cvt_f32_ubyteN directly:
+  // w & 0x0f0f0f0f holds elements (0, 4, 1, 5), (w >> 4) & 0x0f0f0f0f elements (2, 6, 3, 7) in bytes 0..3.
   static __device__ __forceinline__ bf16x8 run(uint32_t w, uint32_t zs) {
     const float s = __uint_as_float(zs << 16);
-    const float z = __uint_as_float(zs & 0xffff0000u) - 128.f;  // exact
+    const float nzs = -((__uint_as_float(zs & 0xffff0000u) - 128.f) * s);   // -(z * s), exact
+    const uint32_t a = w & 0x0f0f0f0fu, b = (w >> 4) & 0x0f0f0f0fu;
     uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float a = (float)((w >> (4 * i)) & 0xFu);
-      const float b = (float)((w >> (4 * i + 16)) & 0xFu);
-      o[i] = pack2<bf16_t>((a - z) * s, (b - z) * s);
-    }
+    o[0] = pack2<bf16_t>(fmaf(ub<0>(a), s, nzs), fmaf(ub<2>(a), s, nzs));
+    o[1] = pack2<bf16_t>(fmaf(ub<0>(b), s, nzs), fmaf(ub<2>(b), s, nzs));
+    o[2] = pack2<bf16_t>(fmaf(ub<1>(a), s, nzs), fmaf(ub<3>(a), s, nzs));
+    o[3] = pack2<bf16_t>(fmaf(ub<1>(b), s, nzs), fmaf(ub<3>(b), s, nzs));
     return __builtin_bit_cast(bf16x8, u32x4{o[0], o[1], o[2], o[3]});
   }
 };
@@ -332,6 +336,210 @@ __global__ __launch_bounds__(256) void w4_reduce_kernel(const W4Params p, const 
   *(uint2*)((T*)p.out + m * p.ldo + nb) = make_uint2(pack2<T>(v[0] + bv[0], v[1] + bv[1]), pack2<T>(v[2] + bv[2], v[3] + bv[3]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefill-shaped fused dequant GEMM (M > 512): 256 (m) x 256 (n) output tile per 8-wave workgroup, the dequantisation
+// fused into the MFMA loop -- replaces "materialise W, then a dense GEMM" (awq.py:199-203), which writes and re-reads
+// 2 N K bytes of dense weights per call and hands the product to a library.
+//   * k is walked in phases of 64 elements.  The activation tile [256 rows x 128 B] goes global -> LDS by LDS-DMA into
+//     a ring of 3 stages, two phases ahead (the LDS image of fp8_gemm_xd_kernel: 8-row x 128-B pieces, lane-linear,
+//     two rows per 256-B line, 16-byte position XOR-swizzled with (line & 15) on the source side: conflict-free
+//     ds_read_b128 fragments);
+//   * wave w owns output columns 32 w .. 32 w + 31 (two 16-column tiles) for ALL 256 rows, so every packed weight is
+//     dequantised exactly once per workgroup (a 2 x 4 wave grid would dequantise each twice).  Its packed weights --
+//     two 1-KiB native tiles per 128-k block -- and the 32 (scale, zero) words of the block arrive by LDS-DMA in a
+//     wave-private ring of 3 blocks, two blocks ahead;
+//   * per phase and wave: 2 ds_read_b128 of packed weights -> 4 dequantised fragments (exact (w - z) * s, the bits of
+//     the dense dequant), 32 ds_read_b128 of activations, 64 MFMA 16x16x32 (1024 cycles): the ~64-160 VALU
+//     instructions of the dequant issue in the MFMA shadow;
+//   * counted vmcnt waits (7 entries stay in flight: the next phase's 4 activation pieces + the next block's 3 weight
+//     pieces), ONE barrier per phase; no compiler-tracked vector load inside the loop.
+// LDS: 3 x 32 KiB (activations) + 8 waves x 3 x 2304 B (weights + zs) = 150 KiB.
+// Bound: MFMA (bf16/fp16 16x16x32); per-CU ingest 41 KiB per phase (0.85 us of MFMA) = 48 GB/s.
+template <typename T>
+__global__ __launch_bounds__(512) void w4a16_tile_kernel(const W4Params p, int mblocks, int nblocks,
+                                                         float* __restrict__ slab, int S) {
+  typedef typename Elem<T>::vec8 vec8;
+  constexpr int BM = 256, BN = 256, PB = 128;            // 64 elements of k = 128 bytes of an activation row
+  constexpr int XSTAGE = BM * PB, XR = 3;
+  constexpr int WBLK = 2 * 1024 + 256, WR = 3;           // per wave and 128-k block: 2 native tiles + 64 zs words
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // XCD-aware renumbering: the ~32 tiles resident on one XCD form an 8 (m) x 4 (n) patch that shares both operands
+  // in that XCD's L2 (same scheme as fp8_gemm_tile_kernel)
+  const int nwg = mblocks * nblocks;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nblocks;
+  const int grp = tid / per_group, in_grp = tid % per_group;
+  const int first_m = grp * GM;
+  const int gsz = min(mblocks - first_m, GM);
+  const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+  const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * BN + wave * 32;
+
+  // k range of this workgroup in 128-k blocks (split-K: grid.y = S)
+  const int64_t KB = p.K / 128;
+  const int64_t bper = (KB + S - 1) / S;
+  const int64_t b0 = (int64_t)blockIdx.y * bper;
+  const int64_t b1 = min(KB, b0 + bper);
+  const int nph = (int)(b1 - b0) * 2;
+
+  const uint32_t lds_base = lds_addr_of(smem);
+  const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_base + XR * XSTAGE + wave * (WR * WBLK));
+  // activation DMA geometry (4 of the 32 pieces of a phase per wave)
+  const int dline = lane >> 4, dpos = lane & 15;
+  uint32_t xoff[4], xlds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int line = piece * 4 + dline;
+    const int logical = dpos ^ (line & 15);
+    const int row = line * 2 + (logical >> 3);
+    xoff[i] = (uint32_t)((min(m0 + row, p.M - 1) - m0) * p.ldx * 2 + (logical & 7) * 16);
+    xlds[i] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
+  }
+  // packed weights: native tile (nt, kb) = 1 KiB at ((nt * KB + kb) * 1024); zs word of column n in group row g
+  const int64_t ntiles = p.N / 16;
+  uint32_t woff[2];
+  bool tile_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t nt = n0 / 16 + j;
+    tile_ok[j] = nt < ntiles;
+    woff[j] = (uint32_t)(min(nt, ntiles - 1) * KB * 1024 + lane * 16);
+  }
+  const uint32_t zoff = (uint32_t)(min(n0 + (lane & 31), p.N - 1) * 4);
+  const uint8_t* xbase = (const uint8_t*)p.x + m0 * p.ldx * 2;
+
+  auto issue_x = [&](int ph) __attribute__((always_inline)) {          // phase ph (0-based inside the k range)
+    const uint8_t* xa = uniform_ptr(xbase + (b0 * 128 + (int64_t)ph * 64) * 2);
+    const uint32_t st = (uint32_t)(ph % XR) * XSTAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_s(xoff[i], xa, xlds[i] + st);
+  };
+  auto issue_w = [&](int b) __attribute__((always_inline)) {           // block b (0-based inside the k range)
+    const int64_t kb = b0 + b;
+    const uint8_t* wa = uniform_ptr((const uint8_t*)p.qw + kb * 1024);
+    const uint8_t* za = uniform_ptr(p.zs + (int64_t)((int)kb * 128 / (int)p.group) * p.N);
+    const uint32_t dst = wlds + (uint32_t)(b % WR) * WBLK;
+    glds16_s(woff[0], wa, dst);
+    glds16_s(woff[1], wa, dst + 1024);
+    glds4_s(zoff, za, dst + 2048);
+  };
+  auto frag = [&](const char* base, int row, int slot) __attribute__((always_inline)) -> uint4 {
+    return *(const uint4*)(base + (row >> 1) * 256 + (((((row & 1) << 3) | slot) ^ ((row >> 1) & 15)) * 16));
+  };
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nph > 0) {
+    // issue order: W(0) W(1) X(0) X(1) | iteration ph: [wait X(ph)] barrier, X(ph+2), (ph even) W(ph/2 + 2), compute.
+    // vmcnt entries younger than X(ph) at its wait: X(ph+1) (4) and the one weight block issued after X(ph) (3):
+    // W(ph/2 + 1) for even ph >= 2 (issued in iteration ph-2), W((ph+3)/2) for odd ph (iteration ph-1).
+    const int nblk = nph / 2;
+    issue_w(0);
+    if (nblk > 1) issue_w(1);
+    issue_x(0);
+    if (nph > 1) issue_x(1);
+    for (int ph = 0; ph < nph; ++ph) {
+      const bool x_after = ph + 1 < nph;
+      const bool w_after = ph == 0 ? false : (ph & 1) ? (ph + 3) / 2 < nblk : ph / 2 + 1 < nblk;
+      if (x_after && w_after) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if (x_after) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (w_after) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                    // X(ph) landed everywhere; everyone is done with phase ph-1
+      if (ph + 2 < nph) issue_x(ph + 2);                   // into the stage phase ph-1 used
+      if (!(ph & 1) && ph / 2 + 2 < nblk) issue_w(ph / 2 + 2);   // into the slot block ph/2 - 1 used (wave-private)
+      const char* xb = smem + (ph % XR) * XSTAGE;
+      const char* wb = smem + XR * XSTAGE + wave * (WR * WBLK) + ((ph >> 1) % WR) * WBLK;
+      vec8 wf[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint4 wv = *(const uint4*)(wb + j * 1024 + lane * 16);
+        const uint32_t zsv = *(const uint32_t*)(wb + 2048 + (j * 16 + r16) * 4);
+        const uint32_t lo = (ph & 1) ? wv.z : wv.x, hi = (ph & 1) ? wv.w : wv.y;
+        wf[j][0] = Deq<T>::run(lo, zsv);
+        wf[j][1] = Deq<T>::run(hi, zsv);
+      }
+      // activation fragments in groups of 4 (two m tiles x two k sub-steps), software-pipelined one group ahead: the
+      // ds_read_b128 of group g+1 are issued before the 8 MFMAs of group g, so an MFMA never waits on a read issued
+      // just in front of it (compiler-ordered reads had 1-2 instructions of lookahead: half the MFMA rate)
+      uint4 xg[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xg[0][i] = frag(xb, (i >> 1) * 16 + r16, (i & 1) * 4 + q);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xg[(g + 1) & 1][i] = frag(xb, ((g + 1) * 2 + (i >> 1)) * 16 + r16, (i & 1) * 4 + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = g * 2 + (i >> 1), ks = i & 1;
+          const vec8 xf = __builtin_bit_cast(vec8, xg[g & 1][i]);
+          acc[t][0] = Elem<T>::mfma16(wf[0][ks], xf, acc[t][0]);
+          acc[t][1] = Elem<T>::mfma16(wf[1][ks], xf, acc[t][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds out[m = m0 + 16 t + r16][n = n0 + 16 j + 4 q + r]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (!tile_ok[j]) continue;
+    const int64_t nbase = n0 + j * 16 + 4 * q;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (p.bias && S == 1) ? (float)((const T*)p.bias)[nbase + r] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int64_t m = m0 + t * 16 + r16;
+      if (m >= p.M) continue;
+      if (S > 1) {
+        *(f32x4*)(slab + ((int64_t)blockIdx.y * p.M + m) * p.N + nbase) = acc[t][j];
+      } else {
+        *(uint2*)((T*)p.out + m * p.ldo + nbase) = make_uint2(pack2<T>(acc[t][j][0] + bv[0], acc[t][j][1] + bv[1]),
+                                                             pack2<T>(acc[t][j][2] + bv[2], acc[t][j][3] + bv[3]));
+      }
+    }
+  }
+}
+
+// split-K factor of the tile kernel: only grids that leave most of the chip idle are split (a phase costs ~0.85 us of
+// MFMA per workgroup; the slabs cost a write and a read of S * M * N fp32)
+static int w4_tile_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256), blocks = K / 128;
+  int best = 1;
+  double best_t = (double)cdiv64(tiles, 256) * (double)blocks * 1.7 + 5.0;
+  for (int s = 2; s <= 4 && tiles * s <= 256 && blocks / s >= 8; ++s) {
+    const double t = (double)cdiv64(blocks, s) * 1.7 + (double)s * (double)M * (double)N * 8.0 / 4e6 + 10.0;
+    if (t < best_t) { best_t = t; best = s; }
+  }
+  return best;
+}
+
+template <typename T>
+static void launch_w4_tile(const W4Params& p, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  const int mblocks = (int)cdiv64(p.M, 256), nblocks = (int)cdiv64(p.N, 256);
+  int S = w4_tile_splits(p.M, p.N, p.K);
+  if (S > 1 && (!workspace || workspace_bytes < (int64_t)S * p.M * p.N * (int64_t)sizeof(float))) S = 1;
+  const size_t lds = (size_t)3 * 256 * 128 + (size_t)8 * 3 * 2304;
+  w4a16_tile_kernel<T><<<dim3((unsigned)(mblocks * nblocks), (unsigned)S), 512, lds, st>>>(p, mblocks, nblocks,
+                                                                                             (float*)workspace, S);
+  if (S > 1) w4_reduce_kernel<T><<<(unsigned)cdiv64(p.M * (p.N / 4), 256), 256, 0, st>>>(p, (const float*)workspace, S);
+}
+
 static void w4_plan(int64_t N, int64_t K, int* S, int* ppw) {
   const int64_t nblk = cdiv64(N, 128), nph = K / 128;
   int64_t want = nblk >= 200 ? 1 : 256 / nblk;
@@ -343,9 +551,13 @@ static void w4_plan(int64_t N, int64_t K, int* S, int* ppw) {
   *S = (int)cdiv64(nph, per);
 }
 
-#define W4_CHUNK_MAX_M 512   // batches of 129..512 rows: the decode kernel once per 128-row chunk (above: dequant + dense GEMM)
+#define W4_CHUNK_MAX_M 512   // batches of 129..512 rows: the decode kernel once per 128-row chunk (above: the tile kernel)
 extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M > W4_CHUNK_MAX_M || M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  if (M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  if (M > W4_CHUNK_MAX_M) {
+    const int S = w4_tile_splits(M, N, K);
+    return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+  }
   if (M > 128) M = 128;
   int S, ppw;
   w4_plan(N, K, &S, &ppw);
@@ -418,6 +630,14 @@ extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* z
   p.bias = bias; p.out = out; p.M = M; p.N = N; p.K = K; p.group = group_size; p.ldx = ldx; p.ldo = ldo;
   hipStream_t st = (hipStream_t)stream;
   MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
+  // prefill batches: the 256 x 256 tile kernel with the dequant in the MFMA loop (act-order callers hand in
+  // x[:, perm] -- mi_gather_columns -- so the native k order is the contraction order)
+  if (M > W4_CHUNK_MAX_M && !perm && group_size % 128 == 0) {
+    if (dtype == MI_FP16) launch_w4_tile<f16_t>(p, workspace, workspace_bytes, st);
+    else launch_w4_tile<bf16_t>(p, workspace, workspace_bytes, st);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+  }
   if (dtype == MI_FP16) {
     if (try_w4_xs<f16_t>(p, workspace, workspace_bytes, st)) { MI_CHECK_LAUNCH(); return MI_OK; }
     if (perm) launch_w4<f16_t, true>(p, st); else launch_w4<f16_t, false>(p, st);
@@ -429,11 +649,42 @@ extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* z
   return MI_OK;
 }
 
-// ------------------------------------------------------- native layout -> dense [N, K] (prefill route)
-// Large batches (prefill) are MFMA-bound on a DENSE GEMM, where a fused dequant only adds VALU work per tile: there
-// the reference's own algorithm is the right one -- materialise W once, then one library GEMM (awq.py:199-203).
-// One thread per native dword = 8 consecutive k of one output column, written as one 16-byte store into W^T [N, K]
-// (K contiguous: the NT operand F.linear wants).  Same Deq<T> as the fused kernels: bit-identical weights.
+// ------------------------------------------------------- act-order: activations in native k order
+// GPTQ act-order stores native row k' = checkpoint row perm[k'] (mi_w4_repack), so the contraction needs x[:, perm].
+// out[m][k'] = x[m][perm[k']], 2-byte elements, 4 per thread (one 8-byte store); the source row stays in L1/L2.
+__global__ __launch_bounds__(256) void gather_columns_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ perm,
+                                                             uint16_t* __restrict__ out, int64_t K, int64_t ldx,
+                                                             int64_t ldo) {
+  const int64_t m = blockIdx.y;
+  const int64_t k0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (k0 >= K) return;
+  const uint16_t* xr = x + m * ldx;
+  const int4 pi = *(const int4*)(perm + k0);
+  const uint32_t lo = (uint32_t)xr[pi.x] | ((uint32_t)xr[pi.y] << 16), hi = (uint32_t)xr[pi.z] | ((uint32_t)xr[pi.w] << 16);
+  *(uint2*)(out + m * ldo + k0) = make_uint2(lo, hi);
+}
+
+extern "C" int mi_gather_columns(const void* x, const int32_t* perm, void* out, int64_t M, int64_t K, int64_t ldx,
+                                 int64_t ldo, void* stream) {
+  MI_CHECK_ARG(M >= 0 && K > 0);
+  if (M == 0) return MI_OK;
+  MI_CHECK_ARG(x && perm && out);
+  if (K % 4 != 0 || ldo % 4 != 0 || (((uintptr_t)out | (uintptr_t)perm) & 7) != 0)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_gather_columns: need K %% 4 == 0, ldo %% 4 == 0, 8-byte aligned out / perm");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t m0 = 0; m0 < M; m0 += 65535) {     // grid.y limit
+    const int64_t rows = M - m0 < 65535 ? M - m0 : 65535;
+    gather_columns_kernel<<<dim3((unsigned)cdiv64(K, 1024), (unsigned)rows), 256, 0, st>>>(
+        (const uint16_t*)x + m0 * ldx, perm, (uint16_t*)out + m0 * ldo, K, ldx, ldo);
+  }
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ------------------------------------------------------- native layout -> dense [N, K]
+// The dense W^T [N, K] of a repacked weight (inspection / tests: the product path never materialises it any more --
+// prefill batches run w4a16_tile_kernel).  One thread per native dword = 8 consecutive k of one output column, one
+// 16-byte store.  Same Deq<T> as the fused kernels: bit-identical weights.
 template <typename T>
 __global__ __launch_bounds__(256) void w4_dequant_native_kernel(const uint32_t* __restrict__ qw,
                                                                 const uint32_t* __restrict__ zs, T* __restrict__ w_nk,

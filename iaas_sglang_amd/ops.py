@@ -418,23 +418,29 @@ def w4_repack(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
     return qw, zs, perm
 
 
+def gather_columns(x: torch.Tensor, perm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[:, k] = x[:, perm[k]] (GPTQ act-order: activations in the native k order of w4_repack)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.element_size() == 2
+    assert perm.dtype == torch.int32 and perm.is_contiguous() and perm.numel() == x.shape[1]
+    M, K = x.shape
+    out = torch.empty(M, K, dtype=x.dtype, device=x.device) if out is None else out
+    check(lib.mi_gather_columns(_ptr(x), _ptr(perm), _ptr(out), M, K, x.stride(0), out.stride(0), _stream()),
+          "mi_gather_columns")
+    return out
+
+
 def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, group_size: int,
                perm: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, K] (fp16 / bf16) times the repacked int4 weight: decode batches take the x-stationary fused-dequant
+    kernels, prefill batches (M > 512) the 256 x 256 tile kernel with the dequant in its MFMA loop -- every shape is a
+    hand-written kernel, no library GEMM."""
     assert x.dim() == 2 and x.stride(1) == 1
     M, K = x.shape
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
-    if M > W4_DENSE_MIN_ROWS and K % 128 == 0 and N % 16 == 0:
-        # prefill: MFMA-bound on a dense GEMM -- dequantise once (our kernel, native layout) and hand the product to
-        # the library GEMM, which is the reference's own algorithm (awq.py:199-203: awq_dequantize + torch.matmul)
-        w_nk = w4_dequantize_native(qw, zs, N, K, group_size, x.dtype)
-        xp = x if perm is None else x.index_select(1, perm.to(torch.int64))
-        y = torch.nn.functional.linear(xp, w_nk, bias)
-        if out is None:
-            return y
-        out.copy_(y)
-        return out
+    if perm is not None and M > W4_DENSE_MIN_ROWS and K % 128 == 0:
+        x, perm = gather_columns(x, perm), None        # the tile kernel contracts in native k order
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     ws_bytes = lib.mi_w4a16_gemm_workspace_bytes(M, N, K) if perm is None else 0
     ws = _gemm_workspace(ws_bytes, x.device) if ws_bytes else None
@@ -444,20 +450,13 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, grou
     return out
 
 
-W4_DENSE_MIN_ROWS = 512      # above: dequantise + dense GEMM; up to it: the fused dequant kernels (128-row chunks)
-_w4_dense_scratch: dict = {}
+W4_DENSE_MIN_ROWS = 512      # above: the tile kernel; up to it: the decode kernels (128-row chunks)
 
 
 def w4_dequantize_native(qw: torch.Tensor, zs: torch.Tensor, N: int, K: int, group_size: int,
                          dtype: torch.dtype) -> torch.Tensor:
-    """W^T [N, K] in `dtype` from the load-time native layout (mi_w4_dequantize_native), into a scratch buffer that is
-    reused by the next call on the same device/dtype (the dense weight lives for one GEMM only)."""
-    key = (qw.device, dtype)
-    buf = _w4_dense_scratch.get(key)
-    if buf is None or buf.numel() < N * K:
-        buf = torch.empty(N * K, dtype=dtype, device=qw.device)
-        _w4_dense_scratch[key] = buf
-    w = buf[: N * K].view(N, K)
+    """W^T [N, K] in `dtype` from the load-time native layout (mi_w4_dequantize_native): inspection / tests only."""
+    w = torch.empty(N, K, dtype=dtype, device=qw.device)
     check(lib.mi_w4_dequantize_native(_ptr(qw), _ptr(zs), _ptr(w), N, K, int(group_size), _DT[dtype], _stream()),
           "mi_w4_dequantize_native")
     return w

@@ -298,10 +298,16 @@ int mi_w4a16_gemm(const void* x, const void* qw_native, const void* zs_native,
 /* bytes of split-K scratch mi_w4a16_gemm can use (0: none needed); less is correct but slower */
 int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
-/* W^T [N,K] (K contiguous) = dequant(native-layout weights) in `dtype`: the prefill route -- for batches beyond ~512
- * rows the reference's own algorithm (materialise W once, then one dense library GEMM, awq.py:199-203) beats a fused
- * dequant, which would repeat the VALU work per output tile.  Same bits as the fused kernels' fragments.  With GPTQ
- * act-order the rows are the PERMUTED ones: multiply by x[:, perm].
+/* out[m][k'] = x[m][perm[k']] (2-byte elements): the activations of a GPTQ act-order layer in the native k order of
+ * mi_w4_repack, so that mi_w4a16_gemm can be called with perm == NULL (the tile kernel of prefill batches needs that;
+ * decode batches may pass perm instead).  K % 4 == 0, ldo % 4 == 0.
+ * replaces: the `x[:, g_idx_sort_indices]` reorder of vllm's gptq path (absent here; AutoGPTQ convention). */
+int mi_gather_columns(const void* x, const int32_t* perm, void* out, int64_t M, int64_t K, int64_t ldx, int64_t ldo,
+                      void* stream);
+
+/* W^T [N,K] (K contiguous) = dequant(native-layout weights) in `dtype` -- for inspection and tests; no product path
+ * materialises it (prefill batches run the fused tile kernel inside mi_w4a16_gemm).  Same bits as the fused kernels'
+ * fragments.  With GPTQ act-order the rows are the PERMUTED ones.
  * replaces: awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:186-221 (on our load-time layout). */
 int mi_w4_dequantize_native(const void* qw_native, const void* zs_native, void* w_nk, int64_t N, int64_t K,
                             int64_t group_size, int dtype, void* stream);

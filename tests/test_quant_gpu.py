@@ -130,7 +130,9 @@ def _rand_awq(K, N, g, dtype, gen):
                                      (64, 12288, 4096, 128), (33, 64, 11008, 128),
                                      (64, 22016, 4096, 128), (64, 4096, 11008, 128),      # C4 gate_up / down (Llama-2-7B, batch 64)
                                      (200, 4096, 4096, 128), (512, 1024, 1024, 128),      # 128-row chunks of the decode kernel
-                                     (513, 1024, 2048, 128), (2048, 4096, 1024, 128)])    # dequantise + dense GEMM
+                                     (513, 1024, 2048, 128), (2048, 4096, 1024, 128),     # prefill: the fused tile kernel
+                                     (600, 1024, 4096, 128), (777, 272, 1024, 128),       # split-K slabs; ragged M and N tiles
+                                     (2048, 12288, 4096, 128)])                           # C4 qkv at a 2048-token chunk
 def test_awq_fused_gemm_vs_oracle(dtype, M, N, K, g):
     from iaas_sglang_amd._lib import MI_W4_AWQ
     o_ = ops()

@@ -32,7 +32,7 @@ for p in "ABC":
         kt = glob.glob(f"gpurun_out/{out}.{p}/**/*kernel_trace.csv", recursive=True)
         for r in csv.DictReader(open(kt[0])) if kt else []:
             if any(f in r["Kernel_Name"] for f in filt):
-                grid = r.get("Grid_Size", "?")
+                grid = r.get("Grid_Size") or str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
                 dur[(short(r["Kernel_Name"]), grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 print(f"# {what}")
@@ -41,7 +41,7 @@ for key in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
     c, n = agg[key], calls[key]
     avg = {k: v / max(n[k], 1) for k, v in c.items()}
     wc = avg.get("SQ_WAVE_CYCLES", 0.0)
-    d = dur.get(key) or dur.get((key[0], "?")) or []
+    d = dur.get(key) or []
     print(f"\n{key[0]}  grid={key[1]}  dispatches={n.get('SQ_WAVE_CYCLES', 0)}"
           + (f"  avg_us(under pmc)={sum(d) / len(d) / 1e3:.2f} min_us={min(d) / 1e3:.2f}" if d else ""))
     if wc:
