@@ -54,6 +54,9 @@ def parse():
                     help="sequences of --seq tokens in the prefill leg (-1 = the decode batch: the metric's 128 x 2048; 0 = skip)")
     ap.add_argument("--prefill-chunk", type=int, default=16, help="sequences per EXTEND batch of the prefill leg")
     ap.add_argument("--no-plugin-surface", action="store_true", help="skip the unfused plugin-surface-only step timing")
+    ap.add_argument("--tbo", choices=["auto", "on", "off"], default="auto",
+                    help="two-micro-batch overlap of the decode step (each half of the batch on its own stream, own "
+                         "all-reduce communicator): auto = on for TP > 1 (C5: all-reduce overlapped with attention)")
     ap.add_argument("--kv-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="KV cache dtype: bf16 is BASELINE.json's configuration (the headline); fp8 = e4m3fn pool "
                          "(SURVEY 8f row 1), reported as a variant -- a different workload, not the headline")
@@ -355,6 +358,9 @@ def cpu_baseline(shape, B, S, sample_requests=64, timed_layers=12):
 
 def main():
     a = parse()
+    if os.environ.get("MI_BENCH_WATCHDOG"):     # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MI_BENCH_WATCHDOG"]), exit=True)
     world, rank, local, group = dist_setup(a.gpus, a.dist_backend)
     dev = torch.device("cuda", local)
     from iaas_sglang_amd import harness as H
@@ -381,6 +387,9 @@ def main():
     if a.splits:
         backend._choose_splits = lambda bs, tot, cap=None: a.splits
     custom_ar = make_custom_ar(world, rank, dev, B * shape.hidden * 2) if not a.no_custom_ar else None
+    tbo = a.tbo == "on" or (a.tbo == "auto" and world > 1)
+    # the second micro-batch needs its own staging buffer and barrier flags: a second communicator
+    custom_ar_b = make_custom_ar(world, rank, dev, B * shape.hidden * 2) if (tbo and custom_ar is not None) else None
     static = a.act_scheme == "static"
     cfg = Fp8Config(is_checkpoint_fp8_serialized=static, activation_scheme=a.act_scheme)
     stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=tp, rank=rank, group=group,
@@ -398,6 +407,21 @@ def main():
         logits = stack.forward(hidden, fb.positions, fb, backend)
         torch.argmax(logits, dim=-1, out=out_ids)
 
+    serial_step = step
+    if tbo:
+        backend_b = MiAttnBackend(runner)
+        halves = H.split_decode_batch(fb, backend_b, B // 2)
+        tbo_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        tbo_ars = [custom_ar, custom_ar_b] if custom_ar is not None and custom_ar_b is not None else None
+        if world > 1 and tbo_ars is None:
+            raise SystemExit("--tbo with TP > 1 needs the native all-reduce (two communicators); RCCL calls of two "
+                             "streams would have to be ordered identically on every rank")
+
+        def step():   # noqa: F811  the timed step: both halves of the batch, each on its own stream
+            hidden = torch.index_select(stack.embed, 0, ids)
+            logits = stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], tbo_streams, tbo_ars)
+            torch.argmax(logits, dim=-1, out=out_ids)
+
     def capture(fn):
         """hipGraph of one step (None when capture is impossible, e.g. gloo collectives): eager once on a side stream
         (allocator warm-up, lazy inits), then the capture."""
@@ -412,7 +436,10 @@ def main():
                 fn()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with (custom_ar.capture() if custom_ar is not None else contextlib.nullcontext()):
+            with contextlib.ExitStack() as es:
+                for ca in (custom_ar, custom_ar_b):
+                    if ca is not None:
+                        es.enter_context(ca.capture())
                 with torch.cuda.graph(g):
                     fn()
             return g
@@ -452,6 +479,41 @@ def main():
 
     median_ms = synced_median(run, max(5, a.steps))
 
+    def time_variant(fn):
+        g_ = capture(fn)
+        r_ = g_.replay if g_ is not None else fn
+        for _ in range(a.warmup):
+            r_()
+        barrier_sync(world)
+        t_ = time.perf_counter()
+        for _ in range(a.steps):
+            r_()
+        barrier_sync(world)
+        return max_over_ranks(time.perf_counter() - t_, world, dev) / a.steps * 1e3
+
+    # ---- communication overlap: the serial step beside the two-micro-batch step, and each of them
+    # with the all-reduces dropped (numerically meaningless, timing only): exposed communication = step - that
+    overlap = None
+    if tbo or world > 1:
+        try:
+            overlap = {"mode": ("two micro-batches of %d requests, one HIP stream and one native all-reduce communicator "
+                                "each: the all-reduce of one half runs beside the attention / GEMMs of the other" % (B // 2))
+                               if tbo else "none (serial step)"}
+            if tbo:
+                overlap["ms_per_step_two_batch"] = round(ms_per_step, 4)
+                overlap["ms_per_step_serial"] = round(time_variant(serial_step), 4)
+            if world > 1:
+                H.LlamaStack.comm_disabled = True
+                try:
+                    if tbo:
+                        overlap["exposed_comm_us_two_batch"] = round((ms_per_step - time_variant(step)) * 1e3, 1)
+                    ser = overlap.get("ms_per_step_serial", ms_per_step)
+                    overlap["exposed_comm_us_serial"] = round((ser - time_variant(serial_step)) * 1e3, 1)
+                finally:
+                    H.LlamaStack.comm_disabled = False
+        except Exception as e:  # informational
+            overlap = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- the same step through the plugin surfaces ONLY, as an unmodified model file would drive them
     # (models/llama.py:245-268: norm -> qkv_proj.apply -> rope -> attn.forward -> o_proj.apply -> norm -> gate_up.apply
     # -> act -> down.apply): no fused linear+consumer entry points, no producer-side fp8 quantisation
@@ -459,8 +521,8 @@ def main():
     if not a.no_plugin_surface:
         try:
             H.LlamaStack.fuse_decode_layer, H.Linear.fuse_producer_quant = False, False
-            g2 = capture(step)
-            run2 = g2.replay if g2 is not None else step
+            g2 = capture(serial_step)
+            run2 = g2.replay if g2 is not None else serial_step
             for _ in range(a.warmup):
                 run2()
             barrier_sync(world)
@@ -516,12 +578,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "median_synced_ms": round(median_ms, 4), "tokens_per_s_median_synced": round(B / (median_ms * 1e-3), 1),
         "plugin_surface_only": plugin_only,
+        "overlap": overlap,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "fp8_e4m3 x fp8_e4m3 -> f32 (linears), " + ("fp8 e4m3" if kv8 else "bf16") + " KV/f32 softmax (attention)",
         "data": "synthetic",
         "config": {"workload": f"{shape.name} decode step, per-tensor FP8 linears ({a.act_scheme} activation scale), "
                                f"{'fp8 e4m3' if kv8 else 'bf16'} paged KV page_size=1 {'contiguous' if a.contiguous else 'scattered'} slots, "
                                f"batch {B}, KV seq {S}, {shape.layers} layers, TP={tp}",
                    "global_batch": B, "seq_len": S, "parallelism": f"tp{tp}", "hipgraph": graph is not None,
+                   "two_batch_overlap": bool(tbo),
                    "all_reduce": None if tp == 1 else (
                        ("native-xgmi fused with add+rmsnorm+fp8 quant" if custom_ar.should_fuse_norm(B, shape.hidden, dtype)
                         else "native-xgmi") if custom_ar is not None else "rccl"),

@@ -86,6 +86,19 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Tuning constants.  The shipped library has them compiled in; a developer build (`make TUNING=1`, -DMI_TUNING) lets
+// the environment variable of the same name override each one for A/B runs.  Nothing else in csrc/ reads the
+// environment.
+#ifdef MI_TUNING
+#include <stdlib.h>
+static inline int mi_tune(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+static inline constexpr int mi_tune(const char*, int dflt) { return dflt; }
+#endif
+
 // LDS-DMA (global -> LDS, 16 B per lane, LDS destination = wave-uniform byte address + lane*16) issued
 // from inline asm so that hipcc does NOT know LDS is being written asynchronously: with the builtin it
 // puts an `s_waitcnt vmcnt(0)` in front of every later ds_read that might alias, which drains the whole

@@ -16,7 +16,6 @@
 //                                                        row by DPP row_newbcast
 // HBM-bound: algorithmic bytes = 2 * tokens * Hkv * D * sizeof(T) (+ indices, q, o).
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 struct DecodeParams {
@@ -478,11 +477,6 @@ extern "C" int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_h
   return batch * num_q_heads * num_splits * (v_head_dim + 2) * (int64_t)sizeof(float);
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 template <typename T, int D, int G, int W, bool KV8>
 static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) {
   dim3 grid((unsigned)(p.work ? p.num_work : batch), (unsigned)((p.num_kv_heads + W - 1) / W), (unsigned)(p.work ? 1 : p.num_splits));
@@ -491,7 +485,7 @@ static void launch_decode(const DecodeParams& p, int64_t batch, hipStream_t st) 
 
 template <typename T, int D, int G, bool KV8>
 static void launch_decode_w(const DecodeParams& p, int64_t batch, hipStream_t st) {
-  static const int wenv = env_int("MI_DECODE_W", 0);
+  static const int wenv = mi_tune("MI_DECODE_W", 0);
   const int h = p.num_kv_heads;
   // kv heads (= waves) per workgroup: 8 fills a CU with one workgroup, but a small batch x few splits (long-context
   // decode of a few requests) then leaves most CUs idle -- halve W until the launch has ~one workgroup per CU

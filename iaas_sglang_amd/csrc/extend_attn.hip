@@ -16,7 +16,6 @@
 // conflict-free for both read kinds.
 // Bound: MFMA for long extends, HBM gather for long prefixes.
 #include "common.h"
-#include <stdlib.h>
 
 // decode_attn.hip: merge [rows][heads][splits] partials (unnormalised O, m, l) into o [rows, heads, D]
 MI_INTERNAL int mi_attn_merge_splits(const float* ws_o, const float* ws_ml, void* o, int64_t rows, int64_t num_q_heads,
@@ -348,17 +347,12 @@ void extend_attn_kernel(const ExtendParams p) {
 #undef STAGE_WRITE
 #undef STAGE_LOAD_ONE
 
-static int extend_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 template <typename T, int D, int HG, bool KV8>
 static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
   constexpr int ROW = D * 2 + 32;
   // measured (8 x 2048 causal, Llama-3-8B heads): <1,2> 0.656 ms (419 TFLOP/s, 112 VGPRs: 4 workgroups per CU),
   // <2,4> 0.873 ms (209 VGPRs: 2 per CU) -- occupancy beats fragment reuse here; the big form stays selectable
-  static const int big = extend_env("MI_EXTEND_BIG", 0);
+  static const int big = mi_tune("MI_EXTEND_BIG", 0);
   if (big && max_extend_len > 16) {       // 128 rows x 64-key tiles, double-buffered
     constexpr int BQ = 128 / HG;
     dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)(batch * p.num_splits));

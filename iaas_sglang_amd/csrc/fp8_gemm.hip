@@ -10,7 +10,6 @@
 // consecutive n of one output row (one 8-byte store).
 // Bound at decode (M <= 128): HBM (weights read once); at prefill: MFMA.
 #include "common.h"
-#include <stdlib.h>
 
 typedef long fp8x8_t;  // 8 fp8 values = one MFMA 16x16x32 fp8 operand
 
@@ -690,27 +689,19 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
 }
 
 static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8+: tile-kernel group size override (tuning)
-  static const int r = [] {
-    const char* e = getenv("MI_GEMM_ROTATE");
-    const char* g = getenv("MI_GEMM_TILE_GROUP_M");
-    return (e ? atoi(e) : 1) | ((g ? atoi(g) : 0) << 8);
-  }();
+  static const int r = mi_tune("MI_GEMM_ROTATE", 1) | (mi_tune("MI_GEMM_TILE_GROUP_M", 0) << 8);
   return r;
-}
-static int xs_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
 }
 // waves per workgroup: 8 (two per SIMD: one wave's DMA issue overlaps the other's MFMAs) unless
 // MI_GEMM_XS_NW=4 or the problem is too narrow to give 128-row blocks
 static int xs_waves(int64_t N) {
-  static const int big = xs_env("MI_GEMM_XS_NW", 8);
+  static const int big = mi_tune("MI_GEMM_XS_NW", 8);
   return (big == 8 && N >= 1024) ? 8 : 4;
 }
 
 static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
   const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 2);
-  static const int target = xs_env("MI_GEMM_XS_TARGET", 256);   // one round of workgroups on 256 CUs
+  static const int target = mi_tune("MI_GEMM_XS_TARGET", 256);   // one round of workgroups on 256 CUs
   int64_t want = nblk >= 200 ? 1 : target / nblk;
   if (want < 1) want = 1;
   if (want > nph) want = nph;
@@ -725,12 +716,12 @@ static size_t xs_split_lds(int mt) { return 2 * (size_t)mt * 16 * 256 + 3 * (siz
 template <typename OutT, int MT>
 static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false) {
   const int nw = xs_waves(p.N);
-  static const int nst4 = xs_env("MI_GEMM_XS_STAGES", 3);
+  static const int nst4 = mi_tune("MI_GEMM_XS_STAGES", 3);
   const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
   dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
   const int fs = partial ? 1 : 0;
-  static const int split = xs_env("MI_GEMM_XS_SPLIT", 1);
-  static const int deep = xs_env("MI_GEMM_XD", 1);
+  static const int split = mi_tune("MI_GEMM_XS_SPLIT", 1);
+  static const int deep = mi_tune("MI_GEMM_XD", 1);
   if constexpr (MT == 16) {
     // 129..256 rows in one pass over the weights: 48-KiB stages (x 32 KiB + weights 16 KiB), ring of 3
     fp8_gemm_xd_kernel<OutT, 16, 0, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
@@ -761,7 +752,7 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
 static double tile_time(int64_t M, int64_t N, int64_t K, int* S_out);
 // rows one pass of the decode kernels takes: 256 with the 8-wave deep-ring kernel (MT = 16), else 128
 MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N) {
-  static const int deep = xs_env("MI_GEMM_XD", 1), wide = xs_env("MI_GEMM_XD16", 1);
+  static const int deep = mi_tune("MI_GEMM_XD", 1), wide = mi_tune("MI_GEMM_XD16", 1);
   return (xs_waves(N) == 8 && deep && wide) ? 256 : 128;
 }
 static bool mid_m_chunked(int64_t M, int64_t N, int64_t K) {
@@ -1010,7 +1001,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 // split-K factor of the tile kernel, from the measured rates (us): a k-step of one workgroup costs ~1.3 us of LDS-DMA
 // ingest whatever else runs, the slabs cost a write and a read of S * M * N fp32 at ~4 TB/s
 static double tile_time(int64_t M, int64_t N, int64_t K, int* S_out) {
-  static const int enable = xs_env("MI_GEMM_TILE_SPLITK", 1);
+  static const int enable = mi_tune("MI_GEMM_TILE_SPLITK", 1);
   const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256), steps = K / 128;
   int best = 1;
   double best_t = (double)cdiv64(tiles, 256) * (double)steps * 1.3 + 5.0;
@@ -1186,7 +1177,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
-  static const int deep = xs_env("MI_GEMM_XD", 1);
+  static const int deep = mi_tune("MI_GEMM_XD", 1);
 #define LAUNCH_EPI(TT, MTV)                                                                                    \
   if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \

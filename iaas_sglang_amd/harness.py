@@ -222,6 +222,11 @@ class LlamaStack:
         Returns (out or None, fp8 or None); residual is updated in place.  Same bits either way."""
         M, H = qx.shape[0], self.shape.hidden
         ca = self.custom_ar
+        if self.comm_disabled:      # timing only (bench: exposed communication = step - this): every rank keeps its partial sum
+            h = lin.forward_prequantized(qx, self.dtype)
+            if q_scale is not None:
+                return None, ops.rmsnorm_fp8(h, norm_w, self.shape.rms_eps, q_scale, residual=residual)
+            return ops.rmsnorm(h, norm_w, self.shape.rms_eps, residual=residual), None
         if ca is not None and ca.should_fuse_norm(M, H, self.dtype):
             h = lin.forward_prequantized(qx, self.dtype, out=ca.staging((M, H), self.dtype))
             return ca.all_reduce_add_rmsnorm(h, residual, norm_w, self.shape.rms_eps, q_scale=q_scale,
@@ -244,6 +249,7 @@ class LlamaStack:
             Linear.calibrating = False
 
     fuse_decode_layer = True   # linear + consumer fused forms on decode batches
+    comm_disabled = False      # bench only: drop the TP all-reduces to time the step without communication
 
     def _fused_decode_ok(self, hidden, fb):
         if not (LlamaStack.fuse_decode_layer and Linear.fuse_producer_quant) or Linear.calibrating:
@@ -258,7 +264,7 @@ class LlamaStack:
                     return False
         return True
 
-    def forward_decode_fused(self, hidden, positions, fb, backend):
+    def forward_decode_fused(self, hidden, positions, fb, backend, return_hidden=False):
         """The same layer sequence as forward() with each FP8 linear fused with its consumer:
         norm+quant | qkv+rope+kv-write | attention(+quant) | o+add+norm+quant | gate_up+silu*mul+quant |
         down+add+norm(next layer)+quant  -- 7 launches per layer instead of 15, bit-identical results.
@@ -296,7 +302,43 @@ class LlamaStack:
                 x, qx = L.down.quant_method.apply_add_rmsnorm(L.down, act8, residual, nw, s.rms_eps, ns)
             else:
                 x, qx = self._row_parallel_add_norm(L.down, act8, residual, nw, ns)
+        if return_hidden:          # final-norm output; the caller runs the lm_head (two-micro-batch step: once, after the join)
+            return x
         logits = torch.matmul(x, self.lm_head.t())
+        return tensor_model_parallel_all_gather(logits, self.tp, self.group)
+
+    def forward_decode_two_batch(self, hidden, positions, fbs, backends, streams, custom_ars=None):
+        """Two-micro-batch overlap of a decode step (the behaviour of two_batch_overlap.py:361-615 for a dense model):
+        the batch is split into halves A and B (`fbs`, `backends`: one ForwardBatch + attention backend each, rows
+        [0, nA) and [nA, nA + nB) of `hidden`), each half runs the whole fused layer sequence on its own HIP stream,
+        and the two streams only meet at the start and at the end of the step.  With TP > 1 every half has its own
+        native all-reduce communicator (`custom_ars`: separate staging buffer and barrier flags), so the row-parallel
+        all-reduce of half A -- a latency-bound kernel on at most 64 workgroups that mostly waits for its peers --
+        runs while half B's attention and GEMMs keep the rest of the chip busy, and vice versa.
+        Every kernel of the step computes rows independently, so the logits are bit-identical to the serial step.
+        The lm_head (a library GEMM, outside the hot path) and the vocabulary all-gather run ONCE on the joined stream
+        over the whole batch: two library GEMMs side by side on two streams hung the GPU (their persistent kernels
+        share scratch), and one M = B GEMM reads the lm_head weights once instead of twice."""
+        nA = fbs[0].batch_size
+        cur = torch.cuda.current_stream()
+        outs = []
+        saved = self.custom_ar
+        try:
+            for i, (lo, hi) in enumerate(((0, nA), (nA, hidden.shape[0]))):
+                streams[i].wait_stream(cur)
+                with torch.cuda.stream(streams[i]):
+                    if custom_ars is not None:
+                        self.custom_ar = custom_ars[i]
+                    backends[i].init_forward_metadata(fbs[i])
+                    outs.append(self.forward_decode_fused(hidden[lo:hi], positions[lo:hi], fbs[i], backends[i],
+                                                          return_hidden=True))
+        finally:
+            self.custom_ar = saved
+        for st in streams:
+            cur.wait_stream(st)
+        for o in outs:
+            o.record_stream(cur)       # allocated on a side stream, consumed on the joined one
+        logits = torch.matmul(torch.cat(outs, dim=0), self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)
 
     def forward(self, hidden, positions, fb, backend, last_token_logits=None):
@@ -350,6 +392,21 @@ class LlamaStack:
             x = x[torch.cumsum(last_token_logits.to(torch.int64), 0) - 1]
         logits = torch.matmul(x, self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)   # logits_processor.py:464-477
+
+
+def split_decode_batch(fb, backend_b, n_first):
+    """The two halves of a decode ForwardBatch for forward_decode_two_batch: requests [0, n_first) keep `fb.attn_backend`,
+    the rest get `backend_b` (each backend owns the metadata of its half)."""
+    halves = []
+    for lo, hi, be in ((0, n_first, fb.attn_backend), (n_first, fb.batch_size, backend_b)):
+        lens_cpu = fb.seq_lens_cpu[lo:hi]
+        halves.append(SimpleNamespace(forward_mode=fb.forward_mode, batch_size=hi - lo,
+                                      req_pool_indices=fb.req_pool_indices[lo:hi].contiguous(),
+                                      seq_lens=fb.seq_lens[lo:hi].contiguous(), seq_lens_sum=int(lens_cpu.sum()),
+                                      seq_lens_cpu=lens_cpu, out_cache_loc=fb.out_cache_loc[lo:hi].contiguous(),
+                                      req_to_token_pool=fb.req_to_token_pool, token_to_kv_pool=fb.token_to_kv_pool,
+                                      attn_backend=be, spec_info=None, positions=fb.positions[lo:hi].contiguous()))
+    return halves
 
 
 def make_decode_batch(runner, backend, batch, seq_len, device, scattered=True, seed=0, ragged=None):

@@ -356,12 +356,13 @@ _GEMM_WS_RETIRED = []      # outgrown buffers stay alive: a captured hipGraph ma
 
 
 def _gemm_workspace(nbytes: int, device) -> torch.Tensor:
-    """Split-K scratch, one growing buffer per device; stream-ordered use (calls on one stream are serialised, so
-    consecutive GEMMs may share it).  A buffer that is outgrown is retired, never freed: graphs captured at start-up
+    """Split-K scratch, one growing buffer per device and stream; stream-ordered use (calls on one stream are
+    serialised, so consecutive GEMMs may share it).  A buffer that is outgrown is retired, never freed: graphs captured at start-up
     (decode GEMMs, the fused forms, w4a16) keep writing their slabs to the address they were captured with, and a
     later eager prefill GEMM that needs more scratch must not hand that memory back to the caching allocator under
     them.  Growth is geometric, so the retired buffers add up to less than the live one."""
-    key = str(device)
+    # per (device, stream): two streams running GEMMs side by side (two-micro-batch overlap) must not share slabs
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = _GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

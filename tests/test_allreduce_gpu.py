@@ -214,3 +214,61 @@ def test_allreduce_captured_in_graph_and_replayed():
     out = mgr.dict()
     mp.spawn(_graph_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert all(out.get(r) for r in range(2)), dict(out)
+
+
+def _tbo_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.custom_all_reduce import CustomAllreduce
+    from iaas_sglang_amd.quantization import Fp8Config
+    cas = [CustomAllreduce(dist.new_group(backend="gloo"), dev, max_size=1 << 20) for _ in range(2)]
+    ok = not any(c.disabled for c in cas)
+    try:
+        shape, dtype, B, S = H.TINY, torch.bfloat16, 8, 40
+        cfg = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+        runner = H.make_runner(shape, max_reqs=B, ctx=128, pool_tokens=B * S + 8, dtype=dtype, device=dev, tp=world,
+                               fill_kv=True, seed=rank)
+        backend, backend_b = MiAttnBackend(runner), MiAttnBackend(runner)
+        stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, dev, tp=world, rank=rank,
+                             group=dist.group.WORLD, custom_ar=cas[0], weight_range=0.05)
+        fb = H.make_decode_batch(runner, backend, B, S, dev, seed=0)
+        hidden = torch.randn(B, shape.hidden, generator=torch.Generator().manual_seed(3)).to(dtype).to(dev)
+        backend.init_forward_metadata(fb)
+        stack.calibrate_static_input_scales(hidden, fb.positions, fb, backend)
+        pool = runner.token_to_kv_pool
+        kv0 = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+        backend.init_forward_metadata(fb)
+        assert stack._fused_decode_ok(hidden, fb)
+        hidden0 = hidden.clone()             # the step updates its input in place (it is the residual stream)
+        want = stack.forward_decode_fused(hidden, fb.positions, fb, backend).float().cpu()
+        for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+            b.copy_(b0)
+        hidden.copy_(hidden0)
+        halves = H.split_decode_batch(fb, backend_b, B // 2)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        dist.barrier()
+        got = stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], streams, cas)
+        torch.cuda.synchronize()
+        same = torch.equal(got.float().cpu(), want)
+        if not same:
+            print(f"[rank {rank}] two-batch TP step: max diff {(got.float().cpu() - want).abs().max()}", flush=True)
+        ok = ok and same and not any(c.timed_out() for c in cas) and bool(torch.isfinite(want).all())
+    finally:
+        for c in cas:
+            c.close()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_tp2_two_batch_overlap_matches_serial_step():
+    """C5's overlap on a TP=2 decode step (two processes on one GPU): each micro-batch on its own stream with its own
+    native all-reduce communicator, against the serial fused step -- bit-identical logits."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tbo_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert all(out.get(r) for r in range(2)), dict(out)

@@ -291,3 +291,53 @@ def test_tiny_llama_awq_extend_then_decode(monkeypatch):
         return oq.awq_linear(x, c["qweight"], c["scales"], c["qzeros"])
 
     _extend_then_decode(stack, runner, backend, shape, dtype, W, lin, prefix=[0, 33, 0], extend=[37, 5, 64], tol=5e-2)
+
+
+@pytest.mark.parametrize("n_first", [4, 5])
+def test_two_batch_overlap_step_is_bit_identical_to_serial(n_first):
+    """forward_decode_two_batch (each half of the batch on its own stream, its own attention metadata and GEMM scratch)
+    against the serial fused step: every kernel computes rows independently, so the logits and the KV pool agree bit
+    for bit -- eagerly and from a captured graph with two parallel branches."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import Fp8Config
+    shape, dtype, B, S = H.TINY, torch.bfloat16, 8, 70
+    cfg = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+    runner = H.make_runner(shape, max_reqs=B, ctx=128, pool_tokens=B * S + 8, dtype=dtype, device=DEV, fill_kv=True)
+    backend, backend_b = MiAttnBackend(runner), MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, lambda: cfg.get_quant_method(None, ""), dtype, DEV, weight_range=0.05)
+    lens = torch.tensor([70, 3, 41, 64, 17, 70, 1, 33])
+    fb = H.make_decode_batch(runner, backend, B, 0, DEV, seed=0, ragged=lens)
+    hidden = torch.randn(B, shape.hidden, generator=torch.Generator().manual_seed(3)).to(dtype).to(DEV)
+    backend.init_forward_metadata(fb)
+    stack.calibrate_static_input_scales(hidden, fb.positions, fb, backend)
+    pool = runner.token_to_kv_pool
+    kv0 = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    backend.init_forward_metadata(fb)
+    assert stack._fused_decode_ok(hidden, fb)
+    hidden0 = hidden.clone()                 # the step updates its input in place (it is the residual stream)
+    want = stack.forward_decode_fused(hidden, fb.positions, fb, backend)
+    kv_want = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+        b.copy_(b0)
+    halves = H.split_decode_batch(fb, backend_b, n_first)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    hidden.copy_(hidden0)
+    got = stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], streams)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert all(torch.equal(a, b) for a, b in zip(pool.k_buffer + pool.v_buffer, kv_want))
+    # the same step as a hipGraph with two parallel branches
+    out = torch.empty_like(want)
+    graph = torch.cuda.CUDAGraph()
+    hidden.copy_(hidden0)
+    with torch.cuda.graph(graph):
+        out.copy_(stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], streams))
+    for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+        b.copy_(b0)
+    hidden.copy_(hidden0)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert all(torch.equal(a, b) for a, b in zip(pool.k_buffer + pool.v_buffer, kv_want))

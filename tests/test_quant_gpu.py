@@ -261,14 +261,15 @@ def test_captured_gemm_survives_scratch_growth():
     torch.cuda.synchronize()
     with torch.cuda.graph(graph):
         o_.fp8_gemm(a, b.t(), sa, sb, torch.bfloat16, out=out)
-    before = o_._GEMM_WS[str(a.device)]
+    key = (str(a.device), torch.cuda.current_stream(a.device).cuda_stream)
+    before = o_._GEMM_WS[key]
     # a larger eager GEMM (tile kernel, split-K slabs) grows the scratch ...
     big_a = torch.randn(2048, 14336, generator=g).to(FP8).to(DEV)
     big_b = torch.randn(4096, 14336, generator=g).to(FP8).to(DEV)
     need = o_.lib.mi_fp8_gemm_workspace_bytes(2048, 4096, 14336)
     o_._gemm_workspace(max(need, before.numel() + 1), a.device)
     o_.fp8_gemm(big_a, big_b.t(), sa, sb, torch.bfloat16)
-    after = o_._GEMM_WS[str(a.device)]
+    after = o_._GEMM_WS[key]
     assert after.data_ptr() != before.data_ptr() and any(t is before for t in o_._GEMM_WS_RETIRED)
     # ... and other allocations may now land anywhere: the captured graph still owns its slabs
     junk = [torch.full((before.numel(),), 0x7f, dtype=torch.uint8, device=DEV) for _ in range(4)]

@@ -23,4 +23,4 @@ run A SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INS
 run B SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES || echo "pass B failed (counter set not available?)"
 run C FETCH_SIZE || echo "pass C failed"
 cd $root
-python3 tools/pmc_summary.py "$out" "$filt" "$script $*" | tee profiles/$out.txt
+python3 tools/pmc_summary.py "$out" "$filt" "$script $*" | tee gpurun_out/$out.txt   # travels back with gpurun_out/; copy it to profiles/
