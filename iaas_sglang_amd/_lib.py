@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_hotpath.so")
 
-ABI_VERSION = 6          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
+ABI_VERSION = 7          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
 MI_BF16, MI_FP16, MI_F32 = 0, 1, 2
 MI_SCALE_TENSOR, MI_SCALE_ROW = 0, 1
 MI_W4_AWQ, MI_W4_GPTQ = 0, 1
@@ -24,6 +24,8 @@ SIGNATURES = {
     "mi_last_error": (C.c_char_p, []),
     "mi_device_cu_count": (_int, []),
     "mi_kv_indptr": (_int, [_p, _int, _p, _i64, _p]),
+    "mi_kv_page_indptr": (_int, [_p, _int, _i64, _p, _i64, _p]),
+    "mi_kv_page_indices": (_int, [_p, _i64, _p, _p, _int, _p, _p, _i64, _i64, _p]),
     "mi_kv_indices": (_int, [_p, _i64, _p, _p, _int, _p, _p, _p, _i64, _p]),
     "mi_kv_write": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "mi_kv_write_fp8": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _int, _p]),
@@ -35,6 +37,8 @@ SIGNATURES = {
     "mi_decode_attn_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_decode_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
+    "mi_decode_attn_paged": (_int, [_p, _p, _p, _p, _p, _p, _int, _f, _f, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64,
+                                    _i64, _i64, _i64, _i64, _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_decode_attn_fp8out": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                      _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_decode_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,

@@ -33,6 +33,9 @@ class ForwardMetadata:
     mask_indptr: Optional[torch.Tensor] = None
     # decode, sliding-window layers: the same fields over the last min(S, window + 1) keys of every request
     # (window_kv_indptr / window_kv_indices / window_num_kv_splits of triton_backend.py:35-37)
+    page_indptr: Optional[torch.Tensor] = None      # page-granular decode (page_size >= 16): one index per page
+    page_indices: Optional[torch.Tensor] = None
+    page_size: int = 1
     window: Optional["ForwardMetadata"] = None
 
 
@@ -89,6 +92,11 @@ class MiAttnBackend(AttentionBackend):
         sw = getattr(model_runner, "sliding_window_size", None)
         self.sliding_window_size = int(sw) if sw is not None and int(sw) > 0 else None
         self.skip_prefill = skip_prefill
+        # page-granular decode indices when the pool is paged (PagedTokenToKVPoolAllocator hands out page-aligned runs,
+        # allocator.py:407-543): page_size a power of two >= 16; smaller pages keep the token-granular path
+        ps = int(getattr(model_runner, "page_size", 1) or 1)
+        self.page_size = ps if ps >= 16 and ps & (ps - 1) == 0 else 1
+        self.page_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device) if self.page_size > 1 else None
         self.num_draft_tokens = getattr(sa, "speculative_num_draft_tokens", None)
         self.mask_indptr = torch.zeros(max_bs + 1, dtype=torch.int64, device=self.device)
         self.kv_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
@@ -256,6 +264,13 @@ class MiAttnBackend(AttentionBackend):
                                                           getattr(forward_batch, "seq_lens_cpu", None))
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, None, None, splits,
                                                     self._workspace(bs, splits), split_chunk=chunk, work=work)
+            if self.page_size > 1:
+                pages = torch.empty(max(-(-int(forward_batch.seq_lens_sum) // self.page_size) + bs, 1), dtype=torch.int32,
+                                    device=self.device)
+                pi, px = ops.kv_page_tables(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                            self.page_size, self.page_indptr, pages)
+                self.forward_metadata.page_indptr, self.forward_metadata.page_indices = pi, px
+                self.forward_metadata.page_size = self.page_size
             if self.sliding_window_size:
                 self.forward_metadata.window = self._window_decode_metadata(
                     bs, forward_batch.req_pool_indices, forward_batch.seq_lens, int(forward_batch.seq_lens_sum),
@@ -289,6 +304,9 @@ class MiAttnBackend(AttentionBackend):
         self.cuda_graph_workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
         self._gplan = _GraphPlan(max_num_tokens * self.max_kv_splits, self.device)
         self.cuda_graph_plan_buf = self._gplan.buf
+        if self.page_size > 1:
+            self.cuda_graph_page_indices = torch.zeros(max_num_tokens * (-(-self.max_context_len // self.page_size)),
+                                                       dtype=torch.int32, device=self.device)
         if self.sliding_window_size:
             # triton_backend.py:373-381
             wcap = max_num_tokens * min(self.max_context_len, self.sliding_window_size + 1)
@@ -310,8 +328,20 @@ class MiAttnBackend(AttentionBackend):
     def _graph_metadata(self, bs: int, kv_indptr, kv_indices=None, gplan=None) -> ForwardMetadata:
         cap = self._graph_split_cap(bs)
         work, plan = (gplan or self._gplan).views(bs * cap)
-        return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices if kv_indices is None else kv_indices, None, None,
-                               cap, self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
+        md = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices if kv_indices is None else kv_indices, None, None,
+                             cap, self.cuda_graph_workspace, split_chunk=0, work=(work, plan))
+        return self._attach_graph_pages(md) if kv_indices is None else md
+
+    def _attach_graph_pages(self, md: ForwardMetadata) -> ForwardMetadata:
+        if self.page_size > 1:
+            md.page_indptr, md.page_indices, md.page_size = self.page_indptr, self.cuda_graph_page_indices, self.page_size
+        return md
+
+    def _graph_page_tables(self, bs, req_pool_indices, seq_lens):
+        """Capture and replay: page ids into the persistent buffer (two kernels, no allocation, no host sync)."""
+        if self.page_size > 1:
+            ops.kv_page_tables(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.page_size, self.page_indptr,
+                               self.cuda_graph_page_indices)
 
     def _graph_window(self, bs, req_pool_indices, seq_lens, seq_lens_sum, seq_lens_cpu) -> Optional[ForwardMetadata]:
         """Capture and replay of the sliding-window set (update_sliding_window_buffer_cuda_graph,
@@ -337,11 +367,13 @@ class MiAttnBackend(AttentionBackend):
         # the captured launch covers the whole capacity bs x max_kv_splits of the work list; which entries are live,
         # the split count and the split size come from the device-side plan.  A valid plan must be in place for the
         # capture-time warm-up runs too (the capture inputs are fill values: one split per request)
+        self._graph_page_tables(bs, req_pool_indices, seq_lens)
         if self.max_kv_splits > 1:
             self._write_graph_plan(bs, bs * self.get_cuda_graph_seq_len_fill_value(), None)
             self.forward_metadata = self._graph_metadata(bs, kv_indptr)
         else:
-            self.forward_metadata = ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, 1, None)
+            self.forward_metadata = self._attach_graph_pages(
+                ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, None, None, 1, None))
         self.forward_metadata.window = self._graph_window(bs, req_pool_indices, seq_lens,
                                                           bs * self.get_cuda_graph_seq_len_fill_value(), None)
 
@@ -352,6 +384,7 @@ class MiAttnBackend(AttentionBackend):
         # no allocation, no host sync: two kernels into persistent buffers (triton_backend.py:544-566) and the plan
         kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
+        self._graph_page_tables(bs, req_pool_indices, seq_lens)
         if self.max_kv_splits > 1:
             self._write_graph_plan(bs, int(seq_lens_sum), seq_lens_cpu)
         self._graph_window(bs, req_pool_indices, seq_lens, int(seq_lens_sum), seq_lens_cpu)
@@ -406,6 +439,18 @@ class MiAttnBackend(AttentionBackend):
             if md.window is None:
                 raise ValueError("sliding-window layer, but model_runner.sliding_window_size was not set")
             md = md.window
+        if md.page_indptr is not None:           # page-granular indices: same kernel, one index per page
+            fp8_pool = k_buf.element_size() == 1
+            ks, vs = self._kv_scales(layer) if fp8_pool else (1.0, 1.0)
+            o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device) if fp8_out_scale is not None else None
+            o = q.new_empty(q.shape) if o8 is None else None
+            ops.decode_attention_paged(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k_buf, v_buf, md.kv_indptr,
+                                       md.page_indptr, md.page_indices, md.page_size, layer.scaling,
+                                       getattr(layer, "logit_cap", 0.0) or 0.0, md.num_kv_splits, md.workspace,
+                                       o=None if o is None else o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                                       o_fp8=o8, o_scale=fp8_out_scale, k_scale=ks, v_scale=vs,
+                                       split_chunk=md.split_chunk, work=md.work)
+            return o if o8 is None else o8
         if k_buf.element_size() == 1:            # fp8 KV cache
             ks, vs = self._kv_scales(layer)
             q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)

@@ -40,6 +40,12 @@ struct DecodeParams {
   float v_scale;         // fp8 KV: output multiplier (k_scale is folded into sm_scale / scale_log2 by the host)
   uint8_t* o_q;          // optional fp8 copy of o, [B][Hq*D] contiguous, = quant(T-rounded o, *o_qscale)
   const float* o_qscale;
+  // page-granular indices (page_size = 1 << page_shift >= 16 slots, page-aligned allocation): kv_indices holds ONE
+  // entry per page (request b's pages start at page_indptr[b]); token t of the request lives in slot
+  // (page_id[t >> shift] << shift) | (t & (page - 1)).  kv_indptr still counts tokens.  page_indptr == nullptr: the
+  // token-granular form above.
+  const int32_t* page_indptr;
+  int32_t page_shift;
 };
 
 // T-rounded values -> e4m3fn with a static scale (same arithmetic as quant_tensor_kernel mode 1)
@@ -169,7 +175,8 @@ void decode_attn_kernel(const DecodeParams p) {
     }
   }
 
-  const int32_t* idx = p.kv_indices + base;
+  const int32_t* idx = p.kv_indices + (p.page_indptr ? p.page_indptr[b] : base);
+  const int32_t pshift = p.page_indptr ? p.page_shift : 0, pmask = (1 << pshift) - 1;
   typedef typename std::conditional<KV8, uint8_t, T>::type TKV;
   const TKV* kb = (const TKV*)p.k_buf + (int64_t)hk * D + (KV8 ? row * 32 : row * 8);
   const TKV* vb = (const TKV*)p.v_buf + (int64_t)hk * D + (col % LPT) * 8;
@@ -191,7 +198,10 @@ void decode_attn_kernel(const DecodeParams p) {
   // computes, so waiting for an index block never drains K/V loads issued after it.  (vmcnt retires in
   // order: the previous form loaded 5 index dwords per tile AFTER the tile ahead of it and had to drain
   // that tile before the next could be requested -- one tile in flight per wave.)
-  auto load_idx_block = [&](int32_t blk) __attribute__((always_inline)) -> int32_t { return idx[min(start + blk * 64 + lane, end - 1)]; };
+  auto load_idx_block = [&](int32_t blk) __attribute__((always_inline)) -> int32_t {
+    const int32_t t = min(start + blk * 64 + lane, end - 1);
+    return (idx[t >> pshift] << pshift) | (t & pmask);      // token-granular: shift 0, mask 0
+  };
   auto load_tile = [&](Tile& t, int32_t vblk, int j) __attribute__((always_inline)) {   // tile j (0..3) of the block whose indices are vblk
     const int32_t ik = __shfl(vblk, 16 * j + col);
     const TKV* kp = kb + (int64_t)ik * p.stride_k_slot;
@@ -521,7 +531,8 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
                             int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
                             float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work, int64_t num_work,
                             const int32_t* plan, int dtype, void* stream, void* o_fp8, const float* o_scale, bool kv8 = false,
-                            float k_scale = 1.f, float v_scale = 1.f) {
+                            float k_scale = 1.f, float v_scale = 1.f, const int32_t* page_indptr = nullptr,
+                            int64_t page_size = 1) {
   MI_CHECK_ARG(batch >= 0);
   if (batch == 0) return MI_OK;
   MI_CHECK_ARG(q && k_buf && v_buf && (o || o_fp8) && kv_indptr && kv_indices);
@@ -560,6 +571,11 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   p.scale_log2 = p.sm_scale * 1.4426950408889634f;
   p.v_scale = kv8 ? v_scale : 1.f;
   p.o_q = (uint8_t*)o_fp8; p.o_qscale = o_scale;
+  p.page_indptr = page_indptr; p.page_shift = 0;
+  if (page_indptr) {
+    MI_CHECK_ARG(page_size >= 1 && page_size <= (1 << 20) && (page_size & (page_size - 1)) == 0);
+    while ((1ll << p.page_shift) < page_size) ++p.page_shift;
+  }
   hipStream_t st = (hipStream_t)stream;
 
   int rc;
@@ -625,4 +641,22 @@ extern "C" int mi_decode_attn_fp8kv(const void* q, const void* k_buf, const void
   return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, kv_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
                           stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits, split_chunk, work, num_work, plan, dtype,
                           stream, o_fp8, o_scale, true, k_scale, v_scale);
+}
+
+// Page-granular form of the three entry points above: `page_indices` holds one page id per page of every
+// request (request b: page_indptr[b] .. ), kv_indptr still counts tokens; o_fp8 / o_scale and kv8 / k_scale / v_scale as
+// in mi_decode_attn_fp8out / mi_decode_attn_fp8kv (o_fp8 nullable, kv8 = 0 for a bf16 / fp16 pool).
+extern "C" int mi_decode_attn_paged(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                                    void* o_fp8 /* nullable */, const float* o_scale, int kv8, float k_scale,
+                                    float v_scale, const int32_t* kv_indptr, const int32_t* page_indptr,
+                                    const int32_t* page_indices, int64_t page_size, void* workspace, int64_t batch,
+                                    int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                                    int64_t stride_o_tok, int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale,
+                                    float logit_cap, int64_t num_splits, int64_t split_chunk, const int32_t* work,
+                                    int64_t num_work, const int32_t* plan, int dtype, void* stream) {
+  MI_CHECK_ARG(page_indptr != nullptr && page_size >= 1);
+  return decode_attn_impl(q, k_buf, v_buf, o, kv_indptr, page_indices, workspace, batch, num_q_heads, num_kv_heads, head_dim,
+                          stride_q_tok, stride_o_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, num_splits,
+                          split_chunk, work, num_work, plan, dtype, stream, o_fp8, o_scale, kv8 != 0, k_scale, v_scale,
+                          page_indptr, page_size);
 }

@@ -23,7 +23,7 @@ extern "C" int mi_device_cu_count(void) {
 // One workgroup of 1024 threads scans up to any batch in chunks (batch is <= a few thousand).
 template <typename L>
 __global__ __launch_bounds__(1024) void kv_indptr_kernel(const L* __restrict__ lens,
-                                                         int32_t* __restrict__ indptr, int64_t batch) {
+                                                         int32_t* __restrict__ indptr, int64_t batch, int32_t page = 1) {
   __shared__ int32_t wave_sum[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(1024) void kv_indptr_kernel(const L* __restrict__ l
   for (int64_t base = 0; base < batch; base += 1024) {
     int64_t i = base + tid;
     int32_t v = (i < batch) ? (int32_t)lens[i] : 0;
+    if (page > 1) v = (v + page - 1) / page;   // pages instead of tokens
     int32_t x = v;  // inclusive scan inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -61,6 +62,57 @@ extern "C" int mi_kv_indptr(const void* lens, int lens_is_i64, int32_t* kv_indpt
     kv_indptr_kernel<int64_t><<<1, 1024, 0, s>>>((const int64_t*)lens, kv_indptr, batch);
   else
     kv_indptr_kernel<int32_t><<<1, 1024, 0, s>>>((const int32_t*)lens, kv_indptr, batch);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// page_indptr[i+1] = sum_{j<=i} ceil(lens[j] / page_size): where request i's page ids start in the page-index array
+extern "C" int mi_kv_page_indptr(const void* lens, int lens_is_i64, int64_t page_size, int32_t* page_indptr,
+                                 int64_t batch, void* stream) {
+  MI_CHECK_ARG(page_indptr != nullptr && batch >= 0 && page_size >= 1 && page_size <= (1 << 20));
+  MI_CHECK_ARG(batch == 0 || lens != nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  if (lens_is_i64)
+    kv_indptr_kernel<int64_t><<<1, 1024, 0, s>>>((const int64_t*)lens, page_indptr, batch, (int32_t)page_size);
+  else
+    kv_indptr_kernel<int32_t><<<1, 1024, 0, s>>>((const int32_t*)lens, page_indptr, batch, (int32_t)page_size);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// page_indices[page_indptr[b] + j] = req_to_token[row_b, j * page] / page: the page id of the request's j-th page
+// (a paged allocator hands out page-aligned runs: allocator.py:407-543, so the first slot of a page names it)
+template <typename L>
+__global__ __launch_bounds__(256) void kv_page_indices_kernel(const int32_t* __restrict__ req_to_token, int64_t stride,
+                                                              const int64_t* __restrict__ req_pool_indices,
+                                                              const L* __restrict__ lens,
+                                                              const int32_t* __restrict__ page_indptr,
+                                                              int32_t* __restrict__ page_indices, int32_t page) {
+  const int b = blockIdx.y;
+  const int64_t npages = ((int64_t)lens[b] + page - 1) / page;
+  const int32_t* src = req_to_token + req_pool_indices[b] * stride;
+  int32_t* dst = page_indices + page_indptr[b];
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < npages; j += (int64_t)gridDim.x * 256)
+    dst[j] = src[j * page] / page;
+}
+
+extern "C" int mi_kv_page_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                                  const int64_t* req_pool_indices, const void* lens, int lens_is_i64,
+                                  const int32_t* page_indptr, int32_t* page_indices, int64_t batch, int64_t page_size,
+                                  void* stream) {
+  MI_CHECK_ARG(batch >= 0 && batch <= 65535 && page_size >= 1 && page_size <= (1 << 20));
+  if (batch == 0) return MI_OK;
+  MI_CHECK_ARG(req_to_token && req_pool_indices && lens && page_indptr && page_indices && req_to_token_stride > 0);
+  hipStream_t s = (hipStream_t)stream;
+  int chunks = (int)(cdiv64(cdiv64(req_to_token_stride, page_size), 256) < 8 ? cdiv64(cdiv64(req_to_token_stride, page_size), 256) : 8);
+  if (chunks < 1) chunks = 1;
+  dim3 grid(chunks, (unsigned)batch);
+  if (lens_is_i64)
+    kv_page_indices_kernel<int64_t><<<grid, 256, 0, s>>>(req_to_token, req_to_token_stride, req_pool_indices,
+                                                         (const int64_t*)lens, page_indptr, page_indices, (int32_t)page_size);
+  else
+    kv_page_indices_kernel<int32_t><<<grid, 256, 0, s>>>(req_to_token, req_to_token_stride, req_pool_indices,
+                                                         (const int32_t*)lens, page_indptr, page_indices, (int32_t)page_size);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -56,11 +56,12 @@ class AttnLayer:
         self.k_scale = self.v_scale = None
 
 
-def make_kv_pool(size, layer_num, head_num, head_dim, dtype, device, fill_random=False, seed=0, kv_dtype=None):
+def make_kv_pool(size, layer_num, head_num, head_dim, dtype, device, fill_random=False, seed=0, kv_dtype=None,
+                 page_size=1):
     """MHATokenToKVPool (mem_cache/memory_pool.py:176-260), optionally pre-filled with N(0,1) data so that a
     steady-state decode batch can be benchmarked without running the prefill first."""
     from .mem_cache import MHATokenToKVPool
-    pool = MHATokenToKVPool(size, 1, kv_dtype or dtype, head_num, head_dim, layer_num, device)
+    pool = MHATokenToKVPool(size, page_size, kv_dtype or dtype, head_num, head_dim, layer_num, device)
     if fill_random:
         g = torch.Generator(device=device).manual_seed(seed)
         for bufs in zip(pool.k_buffer, pool.v_buffer):
@@ -113,7 +114,7 @@ class Linear(torch.nn.Module):
 
 
 def make_runner(shape: ModelShape, max_reqs, ctx, pool_tokens, dtype, device, tp=1, fill_kv=False, seed=0,
-                max_kv_splits=8, kv_dtype=None):
+                max_kv_splits=8, kv_dtype=None, page_size=1):
     """MockModelRunner-equivalent namespace (test_flashattn_backend.py:15-69, SURVEY 8b list)."""
     Hkv = max(1, shape.num_kv_heads // tp)
     mc = SimpleNamespace(num_attention_heads=shape.num_heads, num_key_value_heads=shape.num_kv_heads,
@@ -122,14 +123,14 @@ def make_runner(shape: ModelShape, max_reqs, ctx, pool_tokens, dtype, device, tp
     from .mem_cache import ReqToTokenPool, TokenToKVPoolAllocator
     r2t = ReqToTokenPool(max_reqs, ctx, device)
     pool = make_kv_pool(pool_tokens, shape.layers, Hkv, shape.head_dim, dtype, device, fill_random=fill_kv, seed=seed,
-                        kv_dtype=kv_dtype)
+                        kv_dtype=kv_dtype, page_size=page_size)
     allocator = TokenToKVPoolAllocator(pool_tokens, pool.dtype, device, pool)
-    sa = SimpleNamespace(triton_attention_num_kv_splits=max_kv_splits, page_size=1,
+    sa = SimpleNamespace(triton_attention_num_kv_splits=max_kv_splits, page_size=page_size,
                          speculative_num_draft_tokens=None, speculative_num_steps=None)
     return SimpleNamespace(device=device, dtype=dtype, model_config=mc, req_to_token_pool=r2t,
                            token_to_kv_pool=pool, token_to_kv_pool_allocator=allocator, sliding_window_size=None,
                            server_args=sa, tp_size=tp, gpu_id=0,
-                           kv_cache_dtype="auto" if kv_dtype is None else "fp8_e4m3", page_size=1)
+                           kv_cache_dtype="auto" if kv_dtype is None else "fp8_e4m3", page_size=page_size)
 
 
 def rope_cache(head_dim, max_pos, base, device):
@@ -416,16 +417,31 @@ def make_decode_batch(runner, backend, batch, seq_len, device, scattered=True, s
     g = torch.Generator(device="cpu").manual_seed(seed)
     lens = torch.full((batch,), seq_len, dtype=torch.int64) if ragged is None else ragged.to(torch.int64)
     total = int(lens.sum())
-    assert total <= runner.token_to_kv_pool.size
-    slots = (torch.randperm(total, generator=g) if scattered else torch.arange(total)) + 1
+    P = int(getattr(runner, "page_size", 1) or 1)
     r2t = runner.req_to_token_pool.req_to_token
-    off = 0
     out_loc = []
-    for i in range(batch):
-        L = int(lens[i])
-        r2t[i, :L] = slots[off: off + L].to(torch.int32).to(device)
-        out_loc.append(int(slots[off + L - 1]))
-        off += L
+    if P > 1:
+        # paged pool (PagedTokenToKVPoolAllocator, allocator.py:407-543): every request owns whole pages, page 0 is the
+        # padding sink, the slots inside a page are consecutive; the pages themselves are scattered (or in order)
+        npages = [-(-int(n) // P) for n in lens]
+        assert (sum(npages) + 1) * P <= runner.token_to_kv_pool.size + P
+        pages = (torch.randperm(sum(npages), generator=g) if scattered else torch.arange(sum(npages))) + 1
+        off = 0
+        for i in range(batch):
+            L = int(lens[i])
+            sl = (pages[off: off + npages[i]].view(-1, 1) * P + torch.arange(P).view(1, -1)).reshape(-1)[:L]
+            r2t[i, :L] = sl.to(torch.int32).to(device)
+            out_loc.append(int(sl[L - 1]))
+            off += npages[i]
+    else:
+        assert total <= runner.token_to_kv_pool.size
+        slots = (torch.randperm(total, generator=g) if scattered else torch.arange(total)) + 1
+        off = 0
+        for i in range(batch):
+            L = int(lens[i])
+            r2t[i, :L] = slots[off: off + L].to(torch.int32).to(device)
+            out_loc.append(int(slots[off + L - 1]))
+            off += L
     fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=batch,
                          req_pool_indices=torch.arange(batch, dtype=torch.int64, device=device),
                          seq_lens=lens.to(device), seq_lens_sum=total, seq_lens_cpu=lens,

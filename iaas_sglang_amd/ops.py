@@ -69,6 +69,30 @@ def kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, lens:
     return out
 
 
+def kv_page_tables(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, lens: torch.Tensor, page_size: int,
+                   page_indptr: Optional[torch.Tensor] = None, page_indices: Optional[torch.Tensor] = None):
+    """(page_indptr int32 [B+1], page_indices int32): one page id per page of every request, for decode_attention's
+    page-granular form (page-aligned allocation, page_size a power of two).  `page_indices` needs room for
+    sum(ceil(len / page_size)) entries (<= B * ceil(max_len / page_size))."""
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and req_pool_indices.is_contiguous()
+    assert lens.dtype in (torch.int32, torch.int64) and lens.is_contiguous()
+    assert page_size >= 1 and page_size & (page_size - 1) == 0
+    B = req_pool_indices.shape[0]
+    if page_indptr is None:
+        page_indptr = torch.empty(B + 1, dtype=torch.int32, device=lens.device)
+    check(lib.mi_kv_page_indptr(_ptr(lens), int(lens.dtype == torch.int64), int(page_size), _ptr(page_indptr), B,
+                                _stream()), "mi_kv_page_indptr")
+    if page_indices is None:
+        page_indices = torch.empty(max(B * (-(-req_to_token.shape[1] // page_size)), 1), dtype=torch.int32,
+                                   device=lens.device)
+    assert page_indices.dtype == torch.int32 and page_indptr.dtype == torch.int32
+    check(lib.mi_kv_page_indices(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _ptr(lens),
+                                 int(lens.dtype == torch.int64), _ptr(page_indptr), _ptr(page_indices), B,
+                                 int(page_size), _stream()), "mi_kv_page_indices")
+    return page_indptr[: B + 1], page_indices
+
+
 def kv_write(k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor, k: torch.Tensor,
              v: torch.Tensor) -> None:
     """k_cache[loc] = k ; v_cache[loc] = v   (set_kv_buffer)."""
@@ -202,6 +226,38 @@ def decode_attention(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, 
                              k_buf.stride(0), v_buf.stride(0), float(sm_scale), float(logit_cap),
                              int(num_splits), int(split_chunk), *_work_args(work), _dt(q), _stream()), "mi_decode_attn")
     return o
+
+
+def decode_attention_paged(q: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, kv_indptr_t: torch.Tensor,
+                           page_indptr: torch.Tensor, page_indices: torch.Tensor, page_size: int, sm_scale: float,
+                           logit_cap: float = 0.0, num_splits: int = 1, workspace: Optional[torch.Tensor] = None,
+                           o: Optional[torch.Tensor] = None, o_fp8: Optional[torch.Tensor] = None,
+                           o_scale: Optional[torch.Tensor] = None, k_scale: float = 1.0, v_scale: float = 1.0,
+                           split_chunk: int = 0, work=None):
+    """Decode attention with one index per PAGE (page-aligned pool, page_size = 2^k): bf16 / fp16 or fp8 pool, optional
+    fp8 copy of the output -- the same kernel, arithmetic and bits as decode_attention / _fp8out / _fp8kv."""
+    B, Hq, D = q.shape
+    Hkv = k_buf.shape[1]
+    kv8 = k_buf.element_size() == 1
+    assert q.stride(2) == 1 and q.stride(1) == D
+    assert k_buf.stride(2) == 1 and k_buf.stride(1) == D and v_buf.stride(2) == 1 and v_buf.stride(1) == D
+    assert kv8 or (k_buf.dtype == q.dtype and v_buf.dtype == q.dtype)
+    assert kv_indptr_t.dtype == torch.int32 and page_indptr.dtype == torch.int32 and page_indices.dtype == torch.int32
+    assert o is not None or o_fp8 is not None
+    if o is not None:
+        assert o.dtype == q.dtype and o.stride(2) == 1 and o.stride(1) == D
+    if o_fp8 is not None:
+        assert o_fp8.dtype == FP8_DTYPE and o_fp8.is_contiguous() and o_scale is not None and o_scale.dtype == torch.float32
+    if num_splits > 1:
+        need = decode_workspace_numel(B, Hq, D, num_splits)
+        assert workspace is not None and workspace.dtype == torch.float32 and workspace.numel() >= need
+    check(lib.mi_decode_attn_paged(_ptr(q), _ptr(k_buf), _ptr(v_buf), _ptr(o), _ptr(o_fp8), _ptr(o_scale), int(kv8),
+                                   float(k_scale), float(v_scale), _ptr(kv_indptr_t), _ptr(page_indptr),
+                                   _ptr(page_indices), int(page_size), _ptr(workspace) if num_splits > 1 else None, B,
+                                   Hq, Hkv, D, q.stride(0), o.stride(0) if o is not None else Hq * D, k_buf.stride(0),
+                                   v_buf.stride(0), float(sm_scale), float(logit_cap), int(num_splits),
+                                   int(split_chunk), *_work_args(work), _dt(q), _stream()), "mi_decode_attn_paged")
+    return o if o is not None else o_fp8
 
 
 def extend_attention(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
@@ -48,6 +48,16 @@ int mi_device_cu_count(void);
 /* kv_indptr[0]=0, kv_indptr[i+1]=sum_{j<=i} lens[j]  (int32 out; lens int32 or int64).
  * replaces: torch.cumsum at triton_backend.py:173-174,303-306. */
 int mi_kv_indptr(const void* lens, int lens_is_i64, int32_t* kv_indptr, int64_t batch, void* stream);
+
+/* Page-granular index tables (page_size > 1, page-aligned allocation -- PagedTokenToKVPoolAllocator,
+ * mem_cache/allocator.py:407-543): page_indptr[i+1] = sum_{j<=i} ceil(lens[j] / page_size);
+ * page_indices[page_indptr[b] + j] = req_to_token[row_b, j * page_size] / page_size.  One entry per PAGE instead of
+ * one per token (the role of kv_indices for mi_decode_attn_paged). */
+int mi_kv_page_indptr(const void* lens, int lens_is_i64, int64_t page_size, int32_t* page_indptr, int64_t batch,
+                      void* stream);
+int mi_kv_page_indices(const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                       const void* lens, int lens_is_i64, const int32_t* page_indptr, int32_t* page_indices,
+                       int64_t batch, int64_t page_size, void* stream);
 
 /* kv_indices[kv_indptr[b] + j] = req_to_token[req_pool_indices[b]*stride + start_b + j], j < lens[b]
  * replaces: create_flashinfer_kv_indices_triton, layers/attention/utils.py:5-41 (bit-exact). */
@@ -137,6 +147,21 @@ int mi_decode_attn(const void* q, const void* k_buf, const void* v_buf, void* o,
                    int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
                    int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype,
                    void* stream);
+
+/* Decode attention with PAGE-granular indices: token t of request b lives in slot
+ * page_indices[page_indptr[b] + t / page_size] * page_size + t % page_size (page_size a power of two); kv_indptr still
+ * counts tokens.  Same kernel, same arithmetic and tile order as the token-granular entry points -- identical bits --
+ * with 1/page_size of the index traffic.  o_fp8/o_scale, kv8/k_scale/v_scale: the _fp8out / _fp8kv variants in one.
+ * replaces: decode over a page_size > 1 pool (the reference expands pages to token indices first,
+ * triton_backend.py:173-186 with allocator.py:407-543). */
+int mi_decode_attn_paged(const void* q, const void* k_buf, const void* v_buf, void* o /* nullable */,
+                         void* o_fp8 /* nullable */, const float* o_scale, int kv8, float k_scale, float v_scale,
+                         const int32_t* kv_indptr, const int32_t* page_indptr, const int32_t* page_indices,
+                         int64_t page_size, void* workspace, int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                         int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok, int64_t stride_k_slot,
+                         int64_t stride_v_slot, float sm_scale, float logit_cap, int64_t num_splits,
+                         int64_t split_chunk, const int32_t* work, int64_t num_work, const int32_t* plan, int dtype,
+                         void* stream);
 
 /* mi_decode_attn with the static per-tensor FP8 quantisation of the FOLLOWING linear (o_proj) fused into the
  * output stage: o_fp8 [B, Hq*D] contiguous = quant(o rounded to `dtype`, *o_scale), bit-identical to

@@ -747,3 +747,109 @@ def test_backend_verify_over_long_prefixes_splits_the_key_range():
                          torch.full((bs,), nd), D ** -0.5, causal=True, custom_mask=custom_mask,
                          mask_indptr=torch.tensor(mptr, dtype=torch.int64), skip_prefix_custom_mask=True)
     torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=4e-3, rtol=2 ** -6)
+
+
+# ---------------------------------------------------------------- page-granular decode
+@pytest.mark.parametrize("page_size", [16, 64])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_paged_decode_matches_token_granular(page_size, dtype):
+    """One index per page instead of one per token: the page tables are bit-exact against the python form, and the
+    decode kernel walks the same slots in the same order -- outputs identical to the token-granular call bit for bit
+    (and so within the oracle tolerance), for unsplit, split and ragged-plan launches."""
+    o_ = ops()
+    g = torch.Generator().manual_seed(page_size)
+    B, Hq, Hkv, D = 7, 8, 2, 128
+    lens = torch.tensor([1, page_size, page_size + 1, 5 * page_size - 3, 700, 33, 2 * page_size], dtype=torch.int64)
+    npages = [-(-int(n) // page_size) for n in lens]
+    pages = torch.randperm(sum(npages) + 5, generator=g)[: sum(npages)] + 1            # page 0 = padding sink
+    ctx = int(lens.max()) + 7
+    r2t = torch.zeros(B + 2, ctx, dtype=torch.int32)
+    rpi = torch.randperm(B + 2, generator=g)[:B].to(torch.int64)
+    off = 0
+    for i in range(B):
+        sl = (pages[off: off + npages[i]].view(-1, 1) * page_size + torch.arange(page_size).view(1, -1)).reshape(-1)
+        r2t[rpi[i], : int(lens[i])] = sl[: int(lens[i])].to(torch.int32)
+        off += npages[i]
+    slots = (int(pages.max()) + 1) * page_size
+    k = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(slots, Hkv, D, generator=g).to(dtype)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    # page tables: bit-exact against the python form
+    pi, px = o_.kv_page_tables(r2t.to(DEV), rpi.to(DEV), lens.to(DEV), page_size)
+    want_pi = torch.tensor([0] + list(torch.tensor(npages).cumsum(0)), dtype=torch.int32)
+    assert torch.equal(pi.cpu(), want_pi)
+    want_px = torch.cat([r2t[rpi[i], : int(lens[i]): page_size] // page_size for i in range(B)])
+    assert torch.equal(px.cpu()[: want_px.numel()], want_px)
+    indptr = o_.kv_indptr(lens.to(DEV))
+    idx = torch.empty(int(lens.sum()), dtype=torch.int32, device=DEV)
+    o_.kv_indices(r2t.to(DEV), rpi.to(DEV), lens.to(DEV), indptr, idx)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    sm = D ** -0.5
+    for splits in (1, 3):
+        ws = torch.empty(max(o_.decode_workspace_numel(B, Hq, D, splits), 1), dtype=torch.float32, device=DEV)
+        o_tok = torch.empty_like(qd)
+        o_.decode_attention(qd, kd, vd, o_tok, indptr, idx, sm, 0.0, splits, ws)
+        o_pg = torch.empty_like(qd)
+        o_.decode_attention_paged(qd, kd, vd, indptr, pi, px, page_size, sm, 0.0, splits, ws, o=o_pg)
+        assert torch.equal(o_pg, o_tok)
+    ref = oa.decode_fp32(q, k, v, r2t, rpi, lens, scaling=sm)
+    torch.testing.assert_close(o_pg.cpu().float(), ref, atol=4e-3, rtol=2 ** -7)
+    # the fp8-output form and the backend's own metadata path
+    qs = torch.tensor([0.05], device=DEV)
+    o8_tok = torch.empty(B, Hq * D, dtype=torch.float8_e4m3fn, device=DEV)
+    o_.decode_attention_fp8out(qd, kd, vd, o8_tok, qs, indptr, idx, sm, 0.0, 1, None)
+    o8_pg = torch.empty(B, Hq * D, dtype=torch.float8_e4m3fn, device=DEV)
+    o_.decode_attention_paged(qd, kd, vd, indptr, pi, px, page_size, sm, 0.0, 1, None, o_fp8=o8_pg, o_scale=qs)
+    assert torch.equal(o8_pg.view(torch.uint8), o8_tok.view(torch.uint8))
+
+
+@pytest.mark.parametrize("page_size", [16, 64])
+def test_backend_decode_on_a_paged_pool(page_size):
+    """MiAttnBackend on a runner with page_size >= 16: decode metadata carries page tables (eager and graph replay) and
+    forward_decode gives the bits of the token-granular backend on the same pool."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    shape, dtype, B = H.TINY, torch.bfloat16, 6
+    lens = torch.tensor([40, 3, 129, 64, 17, 100])
+    out = {}
+    for ps in (page_size, 1):
+        runner = H.make_runner(shape, max_reqs=B, ctx=160, pool_tokens=(sum(-(-int(n) // page_size) for n in lens) + 2) * page_size,
+                               dtype=dtype, device=DEV, fill_kv=True, page_size=page_size)
+        runner.page_size = ps               # same paged pool; ps = 1 makes the backend take the token-granular path
+        backend = MiAttnBackend(runner)
+        assert (backend.page_size > 1) == (ps > 1)
+        fb = H.make_decode_batch(SimpleNamespaceLike(runner, page_size), backend, B, 0, DEV, seed=3, ragged=lens)
+        layer = H.AttnLayer(shape.num_heads, shape.head_dim, shape.head_dim ** -0.5, shape.num_kv_heads, 0)
+        g = torch.Generator().manual_seed(1)
+        q = torch.randn(B, shape.num_heads * shape.head_dim, generator=g).to(dtype).to(DEV)
+        kn = torch.randn(B, shape.num_kv_heads, shape.head_dim, generator=g).to(dtype).to(DEV)
+        vn = torch.randn(B, shape.num_kv_heads, shape.head_dim, generator=g).to(dtype).to(DEV)
+        backend.init_forward_metadata(fb)
+        assert (backend.forward_metadata.page_indptr is not None) == (ps > 1)
+        eager = backend.forward(q, kn, vn, layer, fb)
+        # graph-mode metadata: capture-time fill values, then a replay with the real lengths
+        backend.init_cuda_graph_state(B, B)
+        rpi, sl = fb.req_pool_indices.clone(), torch.ones(B, dtype=torch.int64, device=DEV)
+        backend.init_forward_metadata_capture_cuda_graph(B, B, rpi, sl, None, H.ForwardMode.DECODE, None)
+        o_buf = torch.empty_like(eager)
+        graph = torch.cuda.CUDAGraph()
+        o_buf.copy_(backend.forward(q, kn, vn, layer, fb))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            o_buf.copy_(backend.forward(q, kn, vn, layer, fb))
+        sl.copy_(fb.seq_lens)
+        backend.init_forward_metadata_replay_cuda_graph(B, rpi, sl, int(lens.sum()), None, H.ForwardMode.DECODE, None, lens)
+        graph.replay()
+        torch.cuda.synchronize()
+        out[ps] = (eager.clone(), o_buf.clone())
+    assert torch.equal(out[page_size][0], out[1][0])
+    torch.testing.assert_close(out[page_size][1].float(), out[1][1].float(), atol=4e-3, rtol=2 ** -7)
+    torch.testing.assert_close(out[page_size][1].float(), out[page_size][0].float(), atol=4e-3, rtol=2 ** -7)
+
+
+class SimpleNamespaceLike:
+    """A runner view with another page_size for make_decode_batch (the pool layout stays paged)."""
+
+    def __init__(self, runner, page_size):
+        self.__dict__.update(runner.__dict__)
+        self.page_size = page_size

@@ -20,7 +20,21 @@ pools = [(torch.randn(slots, Hkv, D, device=dev, dtype=torch.float32).to(torch.b
 q = torch.randn(B, Hq, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
 o = torch.empty_like(q)
 g = torch.Generator(device=dev).manual_seed(0)
-idx = (torch.arange(B * S, device=dev) if contig else torch.randperm(B * S, device=dev, generator=g)).to(torch.int32) + 1
+PAGE = int(os.environ.get("PAGE", "1"))          # PAGE >= 16: page-aligned layout (scattered pages), page-granular indices
+if PAGE > 1:
+    assert S % PAGE == 0 and os.environ.get("RAGGED", "0") != "1"
+    npg = B * S // PAGE
+    page_ids = (torch.arange(npg, device=dev) if contig else torch.randperm(npg, device=dev, generator=g)).to(torch.int32)
+    idx = (page_ids.view(-1, 1) * PAGE + torch.arange(PAGE, device=dev, dtype=torch.int32).view(1, -1)).reshape(-1) + 1
+    slots = B * S + 1
+    # page p covers slots p*PAGE+1 .. : shift by one page so that ids line up with (id << shift): use a pool with one extra page
+    idx = idx - 1 + PAGE
+    pools = [(torch.randn(slots + PAGE, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16),
+              torch.randn(slots + PAGE, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16)) for _ in range(npool)]
+    page_indices = page_ids + 1
+    page_indptr = (torch.arange(B + 1, device=dev) * (S // PAGE)).to(torch.int32)
+else:
+    idx = (torch.arange(B * S, device=dev) if contig else torch.randperm(B * S, device=dev, generator=g)).to(torch.int32) + 1
 if os.environ.get("RAGGED", "0") == "1":      # S_i ~ U[1, 2S], mean S (SURVEY 8d ragged variant), same pool size
     gl = torch.Generator().manual_seed(0)
     lens = torch.randint(1, 2 * S + 1, (B,), generator=gl)
@@ -54,18 +68,26 @@ if os.environ.get('WORKLIST', '0') == '1':      # the backend's ragged plan: fix
         WORK, CHUNK = (buf[4:].view(cap, 2), buf[:4]), 0
         os.environ['SPLITS'] = str(be.max_kv_splits)
         print(f'device plan: {wl.shape[0]} live of {cap} entries, splits {ns_}', flush=True)
+def run(k, v, ns, ws):
+    if PAGE > 1 and os.environ.get("PAGED_KERNEL", "1") == "1":
+        ops.decode_attention_paged(q, k, v, indptr, page_indptr, page_indices, PAGE, 1 / math.sqrt(D), 0.0, ns, ws, o=o,
+                                   split_chunk=CHUNK, work=WORK)
+    else:
+        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=CHUNK, work=WORK)
+
+
 for ns in [int(x) for x in os.environ.get("SPLITS", "1,2,4,8").split(",")]:
     ws = torch.empty(max(1, ops.decode_workspace_numel(B, Hq, D, ns)), dtype=torch.float32, device=dev)
     for k, v in pools:
-        ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=CHUNK, work=WORK)
+        run(k, v, ns, ws)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
     e0.record()
     for _ in range(reps):
         for k, v in pools:
-            ops.decode_attention(q, k, v, o, indptr, idx, 1 / math.sqrt(D), 0.0, ns, ws, split_chunk=CHUNK, work=WORK)
+            run(k, v, ns, ws)
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * npool)
-    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} contig={int(contig)} splits={ns} W={os.environ.get('MI_DECODE_W','auto')}: "
+    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} contig={int(contig)} page={PAGE} paged_kernel={os.environ.get('PAGED_KERNEL', '1') if PAGE > 1 else '-'} splits={ns} W={os.environ.get('MI_DECODE_W','auto')}: "
           f"{us:8.1f} us  {abytes/us/1e3:7.1f} GB/s", flush=True)
