@@ -53,6 +53,34 @@ __global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* 
   // row per workgroup): all slab / residual loads of a thread are requested before the first add.
   constexpr int SB = 8;   // slabs per batch of loads
   const float sav = sa[0], sbv = sb[0];
+  // Latency-bound (one row per workgroup, a few dependent round trips): EVERY load of the thread -- the first SB slabs
+  // of all its vectors, the residual and the norm weight -- is requested before the first add, so the kernel pays one
+  // memory latency for them instead of one per vector and one more for the weight.
+  // (hidden sizes up to 4096: two vectors per thread = ~210 VGPRs; wider rows keep one vector's loads at a time)
+  constexpr bool PRE = VPT <= 2;
+  constexpr int NPRE = PRE ? VPT : 1;
+  f32x4 la[NPRE][SB], lb[NPRE][SB];
+  uint4 rres[VPT], wreg[VPT];
+  auto load_first = [&](int i, int slot) __attribute__((always_inline)) {
+    const int64_t c = threadIdx.x + i * 256;
+#pragma unroll
+    for (int s2 = 0; s2 < SB; ++s2)
+      if (s2 < S) {
+        la[slot][s2] = *(const f32x4*)(slab + (s2 * M + row) * H + c * 8);
+        lb[slot][s2] = *(const f32x4*)(slab + (s2 * M + row) * H + c * 8 + 4);
+      }
+  };
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t c = threadIdx.x + i * 256;
+    rres[i] = make_uint4(0, 0, 0, 0);
+    wreg[i] = make_uint4(0, 0, 0, 0);
+    if (c < nvec) {
+      if constexpr (PRE) load_first(i, i);
+      if (residual) rres[i] = *(const uint4*)(residual + row * H + c * 8);
+      wreg[i] = *(const uint4*)(w + c * 8);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int64_t c = threadIdx.x + i * 256;
@@ -60,28 +88,33 @@ __global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* 
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      uint4 rres = make_uint4(0, 0, 0, 0);
-      if (residual) rres = *(const uint4*)(residual + row * H + c * 8);
-      for (int s0 = 0; s0 < S; s0 += SB) {
+      if constexpr (!PRE) load_first(i, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < SB; ++s2)
+        if (s2 < S) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += la[PRE ? i : 0][s2][j]; acc[4 + j] += lb[PRE ? i : 0][s2][j]; }
+        }
+      for (int s0 = SB; s0 < S; s0 += SB) {      // more than SB slabs: further batches, same split order
         f32x4 a[SB], b[SB];
 #pragma unroll
-        for (int s = 0; s < SB; ++s)
-          if (s0 + s < S) {
-            a[s] = *(const f32x4*)(slab + ((s0 + s) * M + row) * H + c * 8);
-            b[s] = *(const f32x4*)(slab + ((s0 + s) * M + row) * H + c * 8 + 4);
+        for (int s2 = 0; s2 < SB; ++s2)
+          if (s0 + s2 < S) {
+            a[s2] = *(const f32x4*)(slab + ((s0 + s2) * M + row) * H + c * 8);
+            b[s2] = *(const f32x4*)(slab + ((s0 + s2) * M + row) * H + c * 8 + 4);
           }
 #pragma unroll
-        for (int s = 0; s < SB; ++s)
-          if (s0 + s < S) {
+        for (int s2 = 0; s2 < SB; ++s2)
+          if (s0 + s2 < S) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += a[s][j]; acc[4 + j] += b[s][j]; }
+            for (int j = 0; j < 4; ++j) { acc[j] += a[s2][j]; acc[4 + j] += b[s2][j]; }
           }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[i][j] = rndT<T>(acc[j] * sav * sbv);
       if (residual) {
         float r[8];
-        unpack8g<T>(rres, r);
+        unpack8g<T>(rres[i], r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] += r[j];
         *(uint4*)(residual + row * H + c * 8) = pack8g<T>(v[i]);
@@ -106,7 +139,7 @@ __global__ __launch_bounds__(256) void slab_add_rmsnorm_fp8_kernel(const float* 
     const int64_t c = threadIdx.x + i * 256;
     if (c < nvec) {
       float wf[8], o[8];
-      unpack8g<T>(*(const uint4*)(w + c * 8), wf);
+      unpack8g<T>(wreg[i], wf);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = rndT<T>(v[i][j] * inv * wf[j]);
       if (out) *(uint4*)(out + row * H + c * 8) = pack8g<T>(o);
@@ -150,10 +183,13 @@ __global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __r
   const int rem = (int)(gid % per_tok);
   const int h = rem / vph, c = rem % vph;
   const int64_t col = (int64_t)h * D + c * 8;
+  // requested first, so the dependent cos/sin loads can go out while the slab loads are still in flight
+  const int64_t pos = (h < Hq + Hkv) ? positions[t] : 0;
+  const int64_t slot = (h >= Hq) ? loc[t] : 0;
   float acc1[8], acc2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
-  constexpr int SB = 4;   // slabs per batch: all loads of a batch are requested before the first add
+  constexpr int SB = 8;   // slabs per batch: all loads of a batch are requested before the first add
   for (int s0 = 0; s0 < S; s0 += SB) {
     f32x4 a[SB], b[SB], e[SB], f[SB];
 #pragma unroll
@@ -174,7 +210,7 @@ __global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 8; ++j) { x1[j] = rndT<T>(acc1[j] * sa[0] * sb[0]); x2[j] = rndT<T>(acc2[j] * sa[0] * sb[0]); }
   if (h < Hq + Hkv) {  // q or k head: rotate
-    const float* cs = cos_sin + positions[t] * D;
+    const float* cs = cos_sin + pos * D;
     const f32x4 c0 = *(const f32x4*)(cs + c * 8), c1 = *(const f32x4*)(cs + c * 8 + 4);
     const f32x4 s0 = *(const f32x4*)(cs + half + c * 8), s1 = *(const f32x4*)(cs + half + c * 8 + 4);
     const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -191,8 +227,8 @@ __global__ __launch_bounds__(256) void slab_rope_kvwrite_kernel(const float* __r
   }
   T* dst;
   if (h < Hq) dst = q_out + t * ldq + (int64_t)h * D;
-  else if (h < Hq + Hkv) dst = k_cache + loc[t] * cache_stride_k + (int64_t)(h - Hq) * D;
-  else dst = v_cache + loc[t] * cache_stride_v + (int64_t)(h - Hq - Hkv) * D;
+  else if (h < Hq + Hkv) dst = k_cache + slot * cache_stride_k + (int64_t)(h - Hq) * D;
+  else dst = v_cache + slot * cache_stride_v + (int64_t)(h - Hq - Hkv) * D;
   *(uint4*)(dst + c * 8) = pack8g<T>(o1);
   *(uint4*)(dst + half + c * 8) = pack8g<T>(o2);
 }
