@@ -347,6 +347,244 @@ void extend_attn_kernel(const ExtendParams p) {
 #undef STAGE_WRITE
 #undef STAGE_LOAD_ONE
 
+// ---------------------------------------------------------------------------------------------
+// Long extends, head_dim 128, bf16 / fp16 pool, plain causal / full attention: the MFMA 32x32x16 form.
+//   Workgroup = 8 waves = HG q heads of ONE kv head x (8 / HG) blocks of 32 tokens; every wave owns a 32-row query
+//   block of one q head, Q in registers (8 B-operand fragments).  Keys are walked in tiles of 128 (four 32-key
+//   sub-tiles), K and V double-buffered in LDS, staged through registers (loads for tile t+1 issued before tile t is
+//   computed, written to the other stage after).  Per 32-key sub-tile and wave:
+//     S^T[key][row] = K . Q^T          8 MFMA 32x32x16, A = K rows by ds_read_b128: each 1-KiB fragment feeds 32 query
+//                                      rows (the 16x16x32 form read one per 16), i.e. half the LDS traffic per flop
+//     softmax                          a lane holds 16 of the 32 keys of ONE query row (column = lane & 31): the row max
+//                                      and sum are in-lane over 16 registers + one exchange with lane ^ 32
+//     O^T[d][row] += V^T . P^T         8 MFMA, A = V^T by ds_read_b64_tr_b16 (two 4-key blocks per fragment), B = P^T
+//                                      straight from the S^T accumulator registers: element j of lane half h of k-step s
+//                                      is key 16 s + 8 (j >> 2) + 4 h + (j & 3), and the V^T blocks are fetched in that
+//                                      same key order (any consistent order gives the same sum)
+//   LDS image of both tiles: plain 256-byte rows, 16-byte chunk c of row r at 16 * (c ^ (((r & 3) << 2) | ((r >> 2) & 3)))
+//   -- conflict-free for the row reads and for the transposed reads (cdna_hip_programming.md T10, image (b)).
+//   Deferred rescale (threshold 2^8, decided before a sub-tile's P is exponentiated), mask arithmetic only on
+//   sub-tiles that cross the diagonal or the end of the key range.
+// Everything else (head_dim 64, fp8 pool, tree mask, sliding window, logit cap, split-KV, short extends) stays on
+// extend_attn_kernel above.  Bound: MFMA (bf16 32x32x16), 1024 MFMA cycles per 64 keys and wave.
+// two floats -> one packed dword of T, one instruction where the ISA has it (round to nearest even, as pack2)
+template <typename T> __device__ __forceinline__ uint32_t pack2_fast(float a, float b) {
+  if constexpr (__is_same(T, bf16_t)) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    return pack2<T>(a, b);
+  }
+}
+
+template <typename T, int HG, int NW>   // NW waves per workgroup: 8 (128-key tiles, one workgroup per CU) or 4 (64-key tiles, two)
+__global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendParams p) {
+  constexpr int D = 128, KT = 16 * NW, ROWB = 256;   // four staging passes of NW * 4 key rows
+  constexpr int RP = NW * 4;
+  constexpr int TB = NW / HG;           // 32-token blocks per workgroup
+  constexpr int BQ = 32 * TB;
+  constexpr int TILE = KT * ROWB;
+  constexpr int STAGE = 2 * TILE;       // K tile, V tile
+  typedef typename Elem<T>::vec8 vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int qb = gridDim.x - 1 - blockIdx.x;   // causal: the blocks with the most keys first
+  const int hgroups = p.group / HG;
+  const int hk = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
+  const int req = blockIdx.z;
+  const int32_t q_start = p.qo_indptr[req];
+  const int32_t ext_len = p.qo_indptr[req + 1] - q_start;
+  const int32_t kv_base = p.kv_indptr[req];
+  const int32_t prefix = p.kv_indptr[req + 1] - kv_base;
+  if (qb * BQ >= ext_len) return;       // whole workgroup, before any barrier
+
+  const int head = hk * p.group + hg * HG + (wave % HG);
+  const int tok0 = qb * BQ + (wave / HG) * 32;
+  const bool wave_active = tok0 < ext_len;
+  const int my_tok = min(tok0 + r, ext_len - 1);
+  const int32_t q_pos = prefix + my_tok;
+
+  // Q fragments (B operand of S^T = K . Q^T): lane -> query row r, dims 16 kk + 8 h .. + 8
+  vec8 qf[8];
+  {
+    const T* qp = (const T*)p.q + (int64_t)(q_start + my_tok) * p.stride_q_tok + (int64_t)head * D + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = __builtin_bit_cast(vec8, *(const uint4*)(qp + 16 * kk));
+  }
+
+  const bool causal = p.causal != 0;
+  const int32_t blk_last = min(ext_len, (qb + 1) * BQ);
+  const int32_t n_keys = prefix + (causal ? blk_last : ext_len);
+  const int32_t n_tiles = (n_keys + KT - 1) / KT;
+  const int32_t wave_keys = causal ? prefix + min(ext_len, tok0 + 32) : n_keys;   // keys this wave can see (exclusive)
+
+  // ---- staging: thread -> 16-byte chunk (tid & 15) of key rows (tid >> 4) and 32 + (tid >> 4) of the tile
+  const int srow = tid >> 4, sch = tid & 15;
+  auto lds_off = [](int row, int ch) __attribute__((always_inline)) -> int {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  };
+  // named registers + macros: register ARRAYS captured by a lambda end up in scratch
+  uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+  const bool same_strides = p.stride_k_slot == p.stride_v_slot && p.stride_kx_tok == p.stride_vx_tok;   // the usual case
+  const int64_t hd_off = (int64_t)hk * D + sch * 8;
+#define X32_LOAD_ONE(tile_, ps_, KR, VR)                                                                            \
+  {                                                                                                                 \
+    const int32_t kp_ = min((tile_) * KT + RP * (ps_) + srow, n_keys - 1);                                          \
+    const bool in_pool_ = kp_ < prefix;                                                                             \
+    const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + kp_] : 0;                                      \
+    const int64_t t_ = q_start + max(kp_ - prefix, 0);                                                              \
+    const int64_t ko_ = (in_pool_ ? slot_ * p.stride_k_slot : t_ * p.stride_kx_tok) + hd_off;                       \
+    const int64_t vo_ = same_strides ? ko_ : (in_pool_ ? slot_ * p.stride_v_slot : t_ * p.stride_vx_tok) + hd_off;  \
+    KR = *(const uint4*)((in_pool_ ? (const T*)p.k_buf : (const T*)p.k_ext) + ko_);                                 \
+    VR = *(const uint4*)((in_pool_ ? (const T*)p.v_buf : (const T*)p.v_ext) + vo_);                                 \
+  }
+#define X32_STAGE_LOAD(tile_)                       \
+  {                                                 \
+    X32_LOAD_ONE(tile_, 0, kreg0, vreg0);           \
+    X32_LOAD_ONE(tile_, 1, kreg1, vreg1);           \
+    X32_LOAD_ONE(tile_, 2, kreg2, vreg2);           \
+    X32_LOAD_ONE(tile_, 3, kreg3, vreg3);           \
+  }
+#define X32_STAGE_WRITE(st_)                                            \
+  {                                                                     \
+    const int o0_ = lds_off(srow, sch), o1_ = lds_off(RP + srow, sch);  \
+    const int o2_ = lds_off(2 * RP + srow, sch), o3_ = lds_off(3 * RP + srow, sch); \
+    *(uint4*)(smem + (st_) * STAGE + o0_) = kreg0;                      \
+    *(uint4*)(smem + (st_) * STAGE + TILE + o0_) = vreg0;               \
+    *(uint4*)(smem + (st_) * STAGE + o1_) = kreg1;                      \
+    *(uint4*)(smem + (st_) * STAGE + TILE + o1_) = vreg1;               \
+    *(uint4*)(smem + (st_) * STAGE + o2_) = kreg2;                      \
+    *(uint4*)(smem + (st_) * STAGE + TILE + o2_) = vreg2;               \
+    *(uint4*)(smem + (st_) * STAGE + o3_) = kreg3;                      \
+    *(uint4*)(smem + (st_) * STAGE + TILE + o3_) = vreg3;               \
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  // lane-constant LDS byte offsets of the two read kinds, computed once: everything that changes inside the tile loop
+  // (stage, sub-tile, k-step, d block) is a compile-time constant added to them (the scheduler otherwise re-derives
+  // the XOR swizzle per read: 12 VALU instructions per MFMA measured, twice the MFMA time)
+  const int xr = ((r & 3) << 2) | ((r >> 2) & 3);                 // K row reads: row 32 sub + r
+  uint32_t kofs[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) kofs[kk] = (uint32_t)(256 * r + 16 * ((2 * kk + h) ^ xr));
+  const int ti = lane & 15, tq = ti >> 2, tp = ti & 3;            // transposed reads: lane 4 tq + tp of its 16-lane group
+  const int tcol = 2 * ((lane >> 4) & 1) + (tp >> 1);             // chunk inside the 32-d block (+ 4 db)
+  uint32_t vlo[4], vhi[4];                                        // blocks at keys 4 h + tq (+ 16 s2 + 32 sub) and 8 on
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    vlo[db] = (uint32_t)(256 * (4 * h + tq) + 16 * ((4 * db + tcol) ^ ((tq << 2) | h)) + 8 * (tp & 1));
+    vhi[db] = (uint32_t)(256 * (4 * h + tq + 8) + 16 * ((4 * db + tcol) ^ ((tq << 2) | (h + 2))) + 8 * (tp & 1));
+  }
+
+  X32_STAGE_LOAD(0);
+  X32_STAGE_WRITE(0);
+  __syncthreads();
+
+  for (int32_t tile = 0; tile < n_tiles; ++tile) {
+    const int st = tile & 1;
+    const bool has_next = tile + 1 < n_tiles;
+    if (has_next) X32_STAGE_LOAD(tile + 1);
+    const char* kl = smem + st * STAGE;
+    const char* vl = kl + TILE;
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      const int32_t kbase = tile * KT + 32 * sub;
+      if (wave_active && kbase < wave_keys) {
+        // ---- S^T = K . Q^T
+        f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // folds into the first MFMA's C = 0
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const vec8 kf = __builtin_bit_cast(vec8, *(const uint4*)(kl + 256 * 32 * sub + kofs[kk]));
+          if constexpr (__is_same(T, bf16_t))
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+          else
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s, 0, 0, 0);
+        }
+        // ---- scale, mask, online softmax: register i of lane half h is key kbase + (i & 3) + 8 (i >> 2) + 4 h
+        const bool all_visible = kbase + 31 < n_keys && (!causal || kbase + 31 <= prefix + tok0);
+        // the raw logits stay in s; the softmax scale rides in the exponent's fma (one VALU per score instead of two)
+        if (!all_visible) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int32_t kp = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = kp < n_keys && (!causal || kp <= q_pos);
+            s[i] = ok ? s[i] : -INFINITY;
+          }
+        }
+        float tm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+        for (int i = 4; i < 16; i += 4) tm = fmaxf(tm, fmaxf(fmaxf(s[i], s[i + 1]), fmaxf(s[i + 2], s[i + 3])));
+        tm = fmaxf(tm, __shfl_xor(tm, 32)) * p.scale_log2;     // scale > 0: max(c x) = c max(x)
+        if (__any(tm > m + 8.0f)) {      // deferred rescale, decided before this sub-tile's P exists
+          const float mn = fmaxf(m, tm);
+          const float mns = (mn == -INFINITY) ? 0.f : mn;
+          const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mns);
+          m = mn;
+          lsum *= alpha;
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[db][i] *= alpha;
+        }
+        const float nmsafe = (m == -INFINITY) ? 0.f : -m;
+        uint32_t pw[2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float p0 = fast_exp2(fmaf(s[8 * s2 + 2 * jj], p.scale_log2, nmsafe));
+            const float p1 = fast_exp2(fmaf(s[8 * s2 + 2 * jj + 1], p.scale_log2, nmsafe));
+            lsum += p0 + p1;
+            pw[s2][jj] = pack2_fast<T>(p0, p1);
+          }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const vec8 pf = __builtin_bit_cast(vec8, u32x4{pw[s2][0], pw[s2][1], pw[s2][2], pw[s2][3]});
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * sub + 16 * s2) + vlo[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * sub + 16 * s2) + vhi[db]));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if constexpr (__is_same(T, bf16_t))
+              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec8, both), pf, acc[db], 0, 0, 0);
+            else
+              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vec8, both), pf, acc[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (has_next) X32_STAGE_WRITE(st ^ 1);
+    __syncthreads();
+  }
+#undef X32_LOAD_ONE
+#undef X32_STAGE_LOAD
+#undef X32_STAGE_WRITE
+
+  // ---- epilogue: lane holds O[row r][d = 32 db + (i & 3) + 8 (i >> 2) + 4 h]
+  lsum += __shfl_xor(lsum, 32);
+  if (wave_active && tok0 + r < ext_len) {
+    const float inv = 1.f / lsum;
+    T* op = (T*)p.o + (int64_t)(q_start + tok0 + r) * p.stride_o_tok + (int64_t)head * D + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(uint2*)(op + 32 * db + 8 * g) = make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
+                                                     pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
+  }
+}
+
 template <typename T, int D, int HG, bool KV8>
 static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
   constexpr int ROW = D * 2 + 32;
@@ -364,8 +602,29 @@ static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_exte
   }
 }
 
+// the 32x32x16 form: its preconditions (see extend_attn32_kernel) and its launch
+template <typename T>
+static bool try_launch_extend32(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
+  static const int enable = mi_tune("MI_EXTEND_32", 1);
+  if (!enable || max_extend_len < 64 || p.custom_mask || p.sliding_window > 0 || p.logit_cap > 0.f || p.num_splits != 1)
+    return false;
+  const int g = p.group;
+#define X32(HGV, NWV)                                                                                                     \
+  {                                                                                                                       \
+    dim3 grid((unsigned)cdiv64(max_extend_len, 32 * NWV / HGV), (unsigned)(p.num_kv_heads * (g / HGV)), (unsigned)batch); \
+    extend_attn32_kernel<T, HGV, NWV><<<grid, NWV * 64, 2 * 2 * 16 * NWV * 256, st>>>(p);                                  \
+  }
+  // (a 4-wave / 64-key-tile form, two workgroups per CU, was 1.6x slower: 1.09 vs 0.67 ms on 8 x 2048 causal)
+  if (g % 8 == 0) X32(8, 8) else if (g % 4 == 0) X32(4, 8) else if (g % 2 == 0) X32(2, 8) else X32(1, 8)
+#undef X32
+  return true;
+}
+
 template <typename T, int D, bool KV8 = false>
 static int launch_extend_g(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
+  if constexpr (D == 128 && !KV8) {
+    if (try_launch_extend32<T>(p, batch, max_extend_len, st)) return MI_OK;
+  }
   const int g = p.group;
   if (g % 4 == 0) launch_extend<T, D, 4, KV8>(p, batch, max_extend_len, st);
   else if (g % 2 == 0) launch_extend<T, D, 2, KV8>(p, batch, max_extend_len, st);
