@@ -79,7 +79,9 @@ template <typename T> __device__ __forceinline__ float round_to(float v) {
 
 // broadcast lane `N` of each 16-lane row to the whole row (gfx90a+ DPP row_newbcast)
 template <int N> __device__ __forceinline__ float row_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, false));
+  // bound_ctrl: every lane has a source under row_newbcast, and with it the compiler need not materialise `old` (a v_mov 0
+  // in front of every DPP move otherwise)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -77,10 +77,21 @@ __device__ __forceinline__ void fp8x8_to_f32(uint32_t lo, uint32_t hi, float (&f
   const cvt_f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
   f[0] = a[0]; f[1] = a[1]; f[2] = b[0]; f[3] = b[1]; f[4] = c[0]; f[5] = c[1]; f[6] = d[0]; f[7] = d[1];
 }
+// two fp32 values that ARE values of T (every e4m3 number is one) -> one packed dword, one instruction
+template <typename T> __device__ __forceinline__ uint32_t pack2_exact(float a, float b) {
+  if constexpr (__is_same(T, bf16_t)) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+  }
+}
 template <typename T> __device__ __forceinline__ typename Elem<T>::vec8 fp8x8_to_frag(uint32_t lo, uint32_t hi) {
   float f[8];
   fp8x8_to_f32(lo, hi, f);
-  const uint4 u = make_uint4(pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3]), pack2<T>(f[4], f[5]), pack2<T>(f[6], f[7]));
+  const uint4 u = make_uint4(pack2_exact<T>(f[0], f[1]), pack2_exact<T>(f[2], f[3]), pack2_exact<T>(f[4], f[5]),
+                             pack2_exact<T>(f[6], f[7]));
   return __builtin_bit_cast(typename Elem<T>::vec8, u);
 }
 template <bool NT> __device__ __forceinline__ uint4 ldg16(const void* p) {
@@ -102,9 +113,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 
 // At least 2 waves per SIMD (<= 256 VGPRs) whatever W is: two 4-wave workgroups or one 8-wave workgroup
 // are then co-resident per CU.  G = 16 (128 accumulator VGPRs) is the exception.
-// KV8: the pool holds fp8 e4m3fn (1 byte per element, strides in bytes).  K rows are fetched as 32 contiguous
-// bytes per lane (lane row r: dims 32r .. 32r+31, two 16-byte loads) and converted to T fragments; MFMA step j
-// then contracts dims 32r + 8j .. +8, so Q uses the same permuted dim order (any order gives the same sum).
+// KV8: the pool holds fp8 e4m3fn (1 byte per element, strides in bytes).  K rows are fetched as two 16-byte loads
+// per lane (lane row r: dims 16r .. 16r+15 and 64+16r .. 64+16r+15, so each load instruction reads 64 contiguous
+// bytes per token) and converted to T fragments; MFMA step j contracts dims 64(j>>1) + 16r + 8(j&1) .. +8, and Q
+// uses the same permuted dim order (any order gives the same sum).
 // V rows are fetched 8 bytes per lane (16 lanes = one 128-byte head row) and converted straight to fp32.
 template <typename T, int D, int G, int W, bool KV8>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(G >= 16 ? 1 : 2)))
@@ -166,11 +178,11 @@ void decode_attn_kernel(const DecodeParams p) {
   // ---- Q fragments (B operand): lane -> qhead col, dims 32*ks + 8*row .. +8
   vec8 qf[KS];
   {
-    const T* q = (const T*)p.q + (int64_t)b * p.stride_q_tok + (int64_t)(hq0 + col) * D + (KV8 ? row * 32 : row * 8);
+    const T* q = (const T*)p.q + (int64_t)b * p.stride_q_tok + (int64_t)(hq0 + col) * D + (KV8 ? row * 16 : row * 8);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 z = make_uint4(0, 0, 0, 0);
-      if (col < group) z = *(const uint4*)(q + (KV8 ? ks * 8 : ks * 32));
+      if (col < group) z = *(const uint4*)(q + (KV8 ? (ks >> 1) * 64 + (ks & 1) * 8 : ks * 32));
       qf[ks] = __builtin_bit_cast(vec8, z);
     }
   }
@@ -178,7 +190,9 @@ void decode_attn_kernel(const DecodeParams p) {
   const int32_t* idx = p.kv_indices + (p.page_indptr ? p.page_indptr[b] : base);
   const int32_t pshift = p.page_indptr ? p.page_shift : 0, pmask = (1 << pshift) - 1;
   typedef typename std::conditional<KV8, uint8_t, T>::type TKV;
-  const TKV* kb = (const TKV*)p.k_buf + (int64_t)hk * D + (KV8 ? row * 32 : row * 8);
+  const TKV* kb = (const TKV*)p.k_buf + (int64_t)hk * D + (KV8 ? row * 16 : row * 8);
+  // slot strides fit 31 bits (checked on the host): slot index x stride is ONE v_mad_u64_u32 per address
+  const uint32_t kstride = (uint32_t)p.stride_k_slot, vstride = (uint32_t)p.stride_v_slot;
   const TKV* vb = (const TKV*)p.v_buf + (int64_t)hk * D + (col % LPT) * 8;
   const int vtok = 4 * row + (col / LPT);  // + TPR * i
 
@@ -191,7 +205,7 @@ void decode_attn_kernel(const DecodeParams p) {
 
   struct Tile {
     uint4 kf[KV8 ? 2 : KS];     // KV8: 32 raw bytes; else KS fragments of 8 T
-    uint4 vv[NLOAD];            // KV8: only .x/.y (8 bytes) are used
+    typename std::conditional<KV8, uint2, uint4>::type vv[NLOAD];   // KV8: 8 bytes per lane and load
   };
   // kv_indices: ONE coalesced load covers 64 tokens (= 4 tiles), lane l holds idx[64*blk + l]; the lanes of
   // a tile pick theirs with ds_bpermute (LDS crossbar, no LDS memory).  Block b+2 is requested while block b
@@ -204,10 +218,10 @@ void decode_attn_kernel(const DecodeParams p) {
   };
   auto load_tile = [&](Tile& t, int32_t vblk, int j) __attribute__((always_inline)) {   // tile j (0..3) of the block whose indices are vblk
     const int32_t ik = __shfl(vblk, 16 * j + col);
-    const TKV* kp = kb + (int64_t)ik * p.stride_k_slot;
+    const TKV* kp = kb + (uint64_t)(uint32_t)ik * kstride;
     if constexpr (KV8) {
       t.kf[0] = ldg16<NT>(kp);
-      t.kf[1] = ldg16<NT>(kp + 16);
+      t.kf[1] = ldg16<NT>(kp + 64);
     } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) t.kf[ks] = ldg16<NT>(kp + ks * 32);
@@ -216,10 +230,9 @@ void decode_attn_kernel(const DecodeParams p) {
     for (int i = 0; i < NLOAD; ++i) {
       const int32_t iv = __shfl(vblk, 16 * j + vtok + TPR * i);
       if constexpr (KV8) {
-        const uint2 u = ldg8<NT>(vb + (int64_t)iv * p.stride_v_slot);
-        t.vv[i] = make_uint4(u.x, u.y, 0, 0);
+        t.vv[i] = ldg8<NT>(vb + (uint64_t)(uint32_t)iv * vstride);
       } else {
-        t.vv[i] = ldg16<NT>(vb + (int64_t)iv * p.stride_v_slot);
+        t.vv[i] = ldg16<NT>(vb + (uint64_t)(uint32_t)iv * vstride);
       }
     }
   };
@@ -246,7 +259,11 @@ void decode_attn_kernel(const DecodeParams p) {
       } else {
         x = sacc[r] * p.scale_log2;
       }
-      sc[r] = (t0 + 4 * row + r < end) ? x : -INFINITY;
+      sc[r] = x;
+    }
+    if (t0 + 16 > end) {   // only the last live tile (and the masked ones behind it) cross the end: a scalar branch
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[r] = (t0 + 4 * row + r < end) ? sc[r] : -INFINITY;
     }
     float tm = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
     tm = fmaxf(tm, __shfl_xor(tm, 16));
@@ -309,19 +326,32 @@ void decode_attn_kernel(const DecodeParams p) {
   int32_t vnext = load_idx_block(1);
   static_for<0, NB>([&](auto ji) {
     constexpr int j = decltype(ji)::value;
-    if (j < ntiles) load_tile(tl[j], vcur, j);
+    load_tile(tl[j], vcur, j);
   });
+  // The body is branch-free: every iteration computes 4 tiles and refills 4 slots.  Tiles past the end are fully
+  // masked (p = 0; the first tile of a non-empty split always holds a live key, so m is finite by then) and their
+  // loads read the split's LAST row (load_idx_block clamps), one cached line.  With `if (tile < ntiles)` around the
+  // refill the slot registers became a phi of "old" and "loaded": the compiler parked the loads in spare registers
+  // and copied them into the slot behind `s_waitcnt vmcnt(0)` -- the ring drained once per tile (fp8 pool) or
+  // every other tile (bf16 pool), one tile in flight per wave instead of NB - 1.
   for (int32_t tb = 0; tb < ntiles; tb += 4) {   // one 64-token index block per iteration
     const int32_t vafter = load_idx_block((tb >> 2) + 2);
     static_for<0, 4>([&](auto ji) {
       constexpr int j = decltype(ji)::value;
       constexpr int slot = j % NB;
-      const int32_t tn = tb + j;
-      if (tn < ntiles) {
-        compute(tl[slot], start + tn * 16);
-        if (tn + NB < ntiles) {
-          if constexpr (j + NB < 4) load_tile(tl[slot], vcur, j + NB);
-          else load_tile(tl[slot], vnext, j + NB - 4);
+      if constexpr (KV8) {
+        compute(tl[slot], start + (tb + j) * 16);
+        __builtin_amdgcn_sched_barrier(0);   // refill after the tile has been consumed, straight into its registers
+        if constexpr (j + NB < 4) load_tile(tl[slot], vcur, j + NB);
+        else load_tile(tl[slot], vnext, j + NB - 4);
+      } else {     // bf16 / fp16 pool: the branch-free body needs more than 256 VGPRs (spills); kept as it was
+        const int32_t tn = tb + j;
+        if (tn < ntiles) {
+          compute(tl[slot], start + tn * 16);
+          if (tn + NB < ntiles) {
+            if constexpr (j + NB < 4) load_tile(tl[slot], vcur, j + NB);
+            else load_tile(tl[slot], vnext, j + NB - 4);
+          }
         }
       }
     });
@@ -550,6 +580,7 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   // 16-byte vector accesses on q/k/v/o rows
   MI_CHECK_ARG(stride_q_tok % 8 == 0 && stride_o_tok % 8 == 0 && stride_k_slot % 8 == 0 &&
                stride_v_slot % 8 == 0);
+  MI_CHECK_ARG(stride_k_slot > 0 && stride_v_slot > 0 && stride_k_slot < (1ll << 31) && stride_v_slot < (1ll << 31));
   MI_CHECK_ARG((((uintptr_t)q | (uintptr_t)k_buf | (uintptr_t)v_buf | (uintptr_t)o) & 15) == 0);
   MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
 

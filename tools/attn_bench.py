@@ -68,7 +68,16 @@ if os.environ.get('WORKLIST', '0') == '1':      # the backend's ragged plan: fix
         WORK, CHUNK = (buf[4:].view(cap, 2), buf[:4]), 0
         os.environ['SPLITS'] = str(be.max_kv_splits)
         print(f'device plan: {wl.shape[0]} live of {cap} entries, splits {ns_}', flush=True)
+KV8 = os.environ.get("KV8", "0") == "1"       # fp8 e4m3 pool (unit scales); token-granular or paged
+if KV8:
+    pools = [(k.to(torch.float8_e4m3fn), v.to(torch.float8_e4m3fn)) for k, v in pools]
+    abytes = 2 * tot * Hkv * D + 2 * B * Hq * D * 2 + 4 * tot
+
+
 def run(k, v, ns, ws):
+    if KV8 and PAGE == 1:
+        ops.decode_attention_fp8kv(q, k, v, indptr, idx, 1 / math.sqrt(D), 1.0, 1.0, 0.0, ns, ws, o=o, split_chunk=CHUNK, work=WORK)
+        return
     if PAGE > 1 and os.environ.get("PAGED_KERNEL", "1") == "1":
         ops.decode_attention_paged(q, k, v, indptr, page_indptr, page_indices, PAGE, 1 / math.sqrt(D), 0.0, ns, ws, o=o,
                                    split_chunk=CHUNK, work=WORK)
