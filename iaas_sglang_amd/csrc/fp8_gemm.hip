@@ -688,8 +688,10 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
   }
 }
 
-static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8+: tile-kernel group size override (tuning)
-  static const int r = mi_tune("MI_GEMM_ROTATE", 1) | (mi_tune("MI_GEMM_TILE_GROUP_M", 0) << 8);
+static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8..15: tile-kernel group size override (tuning);
+                             // bits 16+: tile-kernel L2 prefetch distance in k-steps (0 = off)
+  static const int r = mi_tune("MI_GEMM_ROTATE", 1) | ((mi_tune("MI_GEMM_TILE_GROUP_M", 0) & 0xff) << 8) |
+                       (mi_tune("MI_GEMM_TILE_PF", 3) << 16);
   return r;
 }
 // waves per workgroup: 8 (two per SIMD: one wave's DMA issue overlaps the other's MFMAs) unless
@@ -799,6 +801,14 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
 // up values of the same (row, column) in the same registers, exchanged through the (free) stage buffers: the
 // epilogue writes fp8(silu(gate) * up) [M, I] directly -- bit-identical to the GEMM followed by mi_silu_and_mul_fp8,
 // without writing and re-reading the [M, 2I] intermediate (0.94 GB per gate_up at 16 k tokens).
+// 16-byte streaming (non-temporal) store: the output tile is not read again by this kernel, and written the ordinary way
+// it displaces the operand slabs the other workgroups of the XCD are about to share in L2 (probe, 16384 x 28672 x 4096,
+// persistent loop: 1.57 ms with plain stores, 1.23 ms non-temporal, 1.10 ms with no output at all)
+__device__ __forceinline__ void stream_store16(void* dst, uint4 v) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t st_u32x4;
+  __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w}, (st_u32x4*)dst);
+}
+
 template <typename OutT, int EPI = 0>
 __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks,
                                                             float* __restrict__ slab, int S,
@@ -811,22 +821,19 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const int r16 = lane & 15, q = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
 
-  // XCD-aware renumbering (bijective for any block count)
+  // PERSISTENT over tiles (grid.x = min(tiles, CUs) when S == 1; with split-K every workgroup has one item).
+  // XCD-aware order: hardware deals workgroup ids round-robin to the 8 XCDs, so XCD x owns a contiguous range of the
+  // tile list and its (up to 32) workgroups walk that range together, 32 tiles at a time.  Inside the range the tiles
+  // are grouped GM m-blocks x all n: the ~32 tiles in flight on an XCD form an 8 x 4 patch and share BOTH operands
+  // in that XCD's L2 (12 operand blocks per 32 tiles instead of 33 with m fastest over all of M).
   const int nwg = mblocks * nblocks;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
-  const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-  // grouped order inside an XCD's range: the ~32 tiles resident on an XCD at one time form a GM x (32/GM)
-  // patch (8 m-blocks x 4 n-blocks), so BOTH operands are shared in that XCD's L2 (12 operand blocks per 32
-  // tiles instead of 33 with m fastest over all of M: the activations were re-read from HBM/MALL once per
-  // n-block -- 7.5 GB per gate_up GEMM, which is what bounded the kernel)
-  const int GM = p.rotate >> 8 ? p.rotate >> 8 : 8;
+  const int orig = blockIdx.x, G = gridDim.x;
+  const int xcd = orig & 7, slot = orig >> 3, gx = (G - xcd + 7) >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int xstart = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+  const int xcnt = qd + (xcd < rm ? 1 : 0);
+  const int GM = (p.rotate >> 8) & 0xff ? (p.rotate >> 8) & 0xff : 8;
   const int per_group = GM * nblocks;
-  const int grp = tid / per_group, in_grp = tid % per_group;
-  const int first_m = grp * GM;
-  const int gsz = min(mblocks - first_m, GM);
-  const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
-  const int64_t m0 = (int64_t)mb * BM, n0 = (int64_t)nb * (EPI ? BN / 2 : BN);
   const int64_t Ihalf = p.N / 2;   // EPI only
   // split-K (grid.y = S > 1): this workgroup walks k-steps [kt0, KT) of its tile and leaves raw fp32 partials in
   // slab[blockIdx.y]; fp8_gemm_reduce_kernel sums them and applies the epilogue.  For grids that leave most CUs idle
@@ -835,31 +842,68 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const int64_t kt_per = (KT_all + S - 1) / S;
   const int64_t kt0 = (int64_t)blockIdx.y * kt_per;
   const int64_t KT = min(KT_all, kt0 + kt_per);
+  if (kt0 >= KT) return;        // (host never launches an empty split)
 
   // DMA geometry: piece i (0..31 per operand) covers tile rows 8i..8i+7; lane L -> LDS byte i*1024 + L*16.
   // LDS line pair l = row>>1, position P = L & 15 within it holds logical (rowbit, slot) = P ^ (l & 15).
+  // Wave w issues pieces 4w .. 4w+3 of both operands: a scalar base per operand (block start + k offset) and one
+  // 32-bit lane offset per piece, no vector address arithmetic in the loop.
   const int dline = lane >> 4;             // 0..3: which 256-B line of the piece
   const int dpos = lane & 15;
   const uint32_t lds_base = lds_addr_of(smem);
-#define TL_STAGE(kt_, buf_)                                                                          \
-  {                                                                                                  \
-    const int64_t kb_ = (int64_t)(kt_) * BK;                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      const int piece_ = wave * 4 + i;               /* 0..31 */                                     \
-      const int line_ = piece_ * 4 + dline;          /* LDS line pair index within the tile */       \
-      const int logical_ = dpos ^ (line_ & 15);                                                      \
-      const int row_ = line_ * 2 + (logical_ >> 3);                                                  \
-      const int slot_ = logical_ & 7;                                                                \
-      const uint8_t* xs_ = p.a + min(m0 + row_, p.M - 1) * p.lda + kb_ + slot_ * 16;                 \
-      const int64_t wr_ = EPI ? (row_ < 128 ? n0 + row_ : Ihalf + n0 + (row_ - 128)) : n0 + row_;    \
-      const uint8_t* ws_ = p.b + min(wr_, p.N - 1) * p.ldb + kb_ + slot_ * 16;                       \
-      glds16(xs_, lds_base + (buf_) * STAGE + piece_ * 1024);                                        \
-      glds16(ws_, lds_base + (buf_) * STAGE + TILE + piece_ * 1024);                                 \
-    }                                                                                                \
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_base + wave * 4 * 1024);
+  int prow[4], pslot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int line = (wave * 4 + i) * 4 + dline;
+    const int logical = dpos ^ (line & 15);
+    prow[i] = line * 2 + (logical >> 3);
+    pslot[i] = (logical & 7) * 16;
   }
+  // per tile only scalars: block bases and the last valid row of each operand block (rows past the matrix edge are
+  // clamped onto it); the lane offsets are rebuilt from (prow, pslot) where they are used -- two VALU ops per piece
+  struct TileAddr {
+    int64_t m0, n0;
+    const uint8_t* xblk;
+    const uint8_t* wblk;
+    int xclamp, wclamp;
+  };
+  auto tile_addr = [&](int li, TileAddr& t) __attribute__((always_inline)) {
+    const int tid = xstart + li;
+    const int grp = tid / per_group, in_grp = tid % per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(mblocks - first_m, GM);
+    const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+    t.m0 = (int64_t)mb * BM;
+    t.n0 = (int64_t)nb * (EPI ? BN / 2 : BN);
+    const int64_t w0 = EPI ? (wave < 4 ? t.n0 : Ihalf + t.n0 - 128) : t.n0;     // EPI: waves 4..7 stage the UP rows
+    t.xblk = uniform_ptr(p.a + t.m0 * p.lda);
+    t.wblk = uniform_ptr(p.b + w0 * p.ldb);
+    t.xclamp = __builtin_amdgcn_readfirstlane((int)min((int64_t)255, p.M - 1 - t.m0));
+    t.wclamp = __builtin_amdgcn_readfirstlane((int)min((int64_t)255, p.N - 1 - w0));
+  };
+  const uint32_t lda32 = (uint32_t)p.lda, ldb32 = (uint32_t)p.ldb;      // < 2^24 (host check): 24-bit multiplies
+#define TL_XOFF(t_, i_) (__umul24((uint32_t)min(prow[i_], (t_).xclamp), lda32) + (uint32_t)pslot[i_])
+#define TL_WOFF(t_, i_) (__umul24((uint32_t)min(prow[i_], (t_).wclamp), ldb32) + (uint32_t)pslot[i_])
   // fragment address of (tile row, 16-byte slot): line pair = row>>1, physical pos = ((row&1)*8+slot) ^ (line&15)
 #define TL_FRAG(base_, row_, slot_) \
   (*(const uint4*)((base_) + ((row_) >> 1) * 256 + (((((row_) & 1) << 3) | (slot_)) ^ (((row_) >> 1) & 15)) * 16))
+
+  const int PF = p.rotate >> 16;
+  uint32_t pf_sink = 0;
+  int step = 0;                 // k-steps done by this workgroup: the stage buffer of a k-step is step & 1
+  bool first_issued = false;    // the current tile's first stage was requested during the previous tile's last k-step
+  TileAddr cur, nxt;
+  if (slot < xcnt) tile_addr(slot, cur);
+  for (int li = slot; li < xcnt; li += gx) {
+  const bool more = li + gx < xcnt;
+  // the next tile's first stage can land during this tile's epilogue unless the epilogue needs all of LDS (EPI) --
+  // otherwise the last k-step requests this tile's own first stage again into the free buffer (never read): the loop
+  // body stays one basic block
+  const bool ahead = more && EPI == 0;
+  if (more) tile_addr(li + gx, nxt);
+  else nxt = cur;
+  const int64_t m0 = cur.m0, n0 = cur.n0;
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -867,12 +911,44 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (kt0 < KT) TL_STAGE(kt0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int64_t kt = kt0; kt < KT; ++kt) {
-    const int buf = (int)((kt - kt0) & 1);
-    if (kt + 1 < KT) TL_STAGE(kt + 1, buf ^ 1);
+  // L2 prefetch: a stage completes when its SLOWEST line is back (the DMA pieces of a wave retire in order), and ~20 %
+  // of the lines of every stage miss the XCD's L2.  Each wave therefore touches, PF k-steps ahead, 64 of the tile's 512
+  // operand rows with ONE global_load_dword (one lane = one 128-byte line; waves 0..3 activation rows, 4..7 weight
+  // rows); the value is never read.  It is issued AFTER the stage's DMA, so the counted wait at the end of the k-step
+  // leaves exactly this one load outstanding and only forces the previous one (a full k-step older).
+  const uint8_t* pf_base;
+  uint32_t pf_off;
+  {
+    const int r = (wave & 3) * 64 + lane;
+    if (wave < 4) {
+      pf_base = cur.xblk;
+      pf_off = (uint32_t)((min(m0 + r, p.M - 1) - m0) * p.lda);
+    } else {
+      const int64_t pw0 = EPI ? (r < 128 ? n0 : Ihalf + n0 - 128) : n0;   // uniform per wave (64-row groups)
+      pf_base = p.b + pw0 * p.ldb;
+      pf_off = (uint32_t)((min(pw0 + r, p.N - 1) - pw0) * p.ldb);
+    }
+    pf_base = uniform_ptr(pf_base);
+  }
+  if (!first_issued) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16_s(TL_XOFF(cur, i), cur.xblk + kt0 * BK, lds_piece + (step & 1) * STAGE + i * 1024);
+      glds16_s(TL_WOFF(cur, i), cur.wblk + kt0 * BK, lds_piece + (step & 1) * STAGE + TILE + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int64_t kt = kt0; kt < KT; ++kt, ++step) {
+    const int buf = step & 1;
+    // the next stage is requested piece by piece BETWEEN the first MFMA groups: both waves of a SIMD leave the barrier
+    // together, and with all eight requests up front they spent ~0.3 us issuing DMAs side by side before the first
+    // MFMA -- now one wave's requests run under the other's (and its own) MFMAs.
+    const bool last = kt + 1 == KT, from_next = last && ahead;
+    const int64_t kn = last ? kt0 : kt + 1;
+    const uint8_t* xs = (from_next ? nxt.xblk : cur.xblk) + kn * BK;
+    const uint8_t* ws = (from_next ? nxt.wblk : cur.wblk) + kn * BK;
+    const int xcl = from_next ? nxt.xclamp : cur.xclamp, wcl = from_next ? nxt.wclamp : cur.wclamp;
     const char* xb = smem + buf * STAGE;
     const char* wb = xb + TILE;
     i32x8 wf[4];
@@ -887,15 +963,23 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       const int row = wm * 128 + i * 16 + r16;
       const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
       const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+      if (i < 4) {
+        glds16_s(__umul24((uint32_t)min(prow[i], xcl), lda32) + (uint32_t)pslot[i], xs, lds_piece + (buf ^ 1) * STAGE + i * 1024);
+        glds16_s(__umul24((uint32_t)min(prow[i], wcl), ldb32) + (uint32_t)pslot[i], ws, lds_piece + (buf ^ 1) * STAGE + TILE + i * 1024);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      if (i == 3)   // `pf_sink` is tied in and out: its register stays reserved for the whole loop (the load lands late)
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_off), "s"(pf_base + min(kt + PF, KT - 1) * BK) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // everything but the prefetch just issued
     __syncthreads();
   }
-#undef TL_STAGE
-#undef TL_FRAG
+  first_issued = ahead;
+  // the stage buffer of the last k-step is free for the epilogue; with `ahead` the other one holds the next tile's
+  // first stage
+  char* const free_buf = smem + ((step - 1) & 1) * STAGE;
 
   // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
   if constexpr (EPI == 1) {
@@ -919,34 +1003,67 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       }
     }
     __syncthreads();
-    if (up) return;
-    const float qs = *epi.q_scale;
-    const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+    // gate waves: the quantised words of their 128 x 64 outputs, in registers
+    uint32_t wq[8][4];
+    if (!up) {
+      const float qs = *epi.q_scale;
+      const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 16 + 4 * q;
-      if (col >= Ihalf) continue;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 16 + r16;
-        if (m >= p.M) continue;
-        const f32x4 u = xch[((wm * 2 + wn) * 32 + i * 4 + j) * 64 + lane];
-        float o[4];
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 u = xch[((wm * 2 + wn) * 32 + i * 4 + j) * 64 + lane];
+          float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = acc[i][j][r];
-          o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
-          o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+          for (int r = 0; r < 4; ++r) {
+            const float g = acc[i][j][r];
+            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+            o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+          }
+          uint32_t w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+          wq[i][j] = w;
         }
-        uint32_t w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
-        *(uint32_t*)(epi.q_out + m * Ihalf + col) = w;
+    }
+    if (n0 + 128 <= Ihalf && (Ihalf & 15) == 0 && ((uintptr_t)epi.q_out & 15) == 0) {
+      // full tiles leave as whole 128-byte lines (the tile's 128 fp8 columns of a row), staged per 128-row half in
+      // the exchange buffer once every gate wave has read its partner's values: [128 rows][128 B], 16-byte chunk c
+      // of row R at position c ^ (R & 7).  Straight from the MFMA layout it was 4-byte stores, 16 rows x 16 B each.
+      __syncthreads();
+      char* stg = smem + wm * 16384;
+      if (!up) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int row = i * 16 + r16;
+            *(uint32_t*)(stg + row * 128 + (((wn * 4 + j) ^ (row & 7)) << 4) + q * 4) = wq[i][j];
+          }
+      }
+      __syncthreads();
+      const int pr = lane >> 3, pc = lane & 7;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {       // the four waves of this half (gate and up) take 32 rows each
+        const int row = wn * 32 + ps * 8 + pr;
+        const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
+        const int64_t m = m0 + wm * 128 + row;
+        if (m < p.M) stream_store16(epi.q_out + m * Ihalf + n0 + pc * 16, v);
+      }
+    } else if (!up) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 16 + 4 * q;
+        if (col >= Ihalf) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t m = m0 + wm * 128 + i * 16 + r16;
+          if (m >= p.M) continue;
+          *(uint32_t*)(epi.q_out + m * Ihalf + col) = wq[i][j];
+        }
       }
     }
-    return;
-  }
-  if (S > 1) {
+  } else if (S > 1) {
     float* sb = slab + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -965,36 +1082,87 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
         }
       }
     }
-    return;
-  }
+  } else if (n0 + BN <= p.N && (p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0) {
+    // Full tiles: the wave's 128 x 64 outputs go through 8 KiB of the free stage buffer, 64 rows at a time, and leave
+    // as whole 128-byte lines, 8 rows per (non-temporal) store instruction; the stores drain under the next tile's
+    // first k-steps.  Straight from the MFMA layout a lane owns 4 consecutive n of one row -- 8-byte stores, 16 rows x
+    // 32 B per instruction, and with one workgroup per tile every epilogue also paid a workgroup launch and an exposed
+    // first stage: 0.74 of the 1.95 ms of a 16384 x 28672 x 4096 GEMM (probe: tools/src/lds_fill.hip; k-loop alone
+    // 1.21 ms, persistent with these stores 1.23 ms).  LDS image: [64 rows][128 B], 16-byte chunk c of row R at
+    // position c ^ (R & 7) (the 8-byte writes of the MFMA layout then spread over all banks).
+    char* stg = free_buf + wave * 8192;
+    const int pr = lane >> 3, pc = lane & 7;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
-    float sbv[4], bv[4];
+    for (int h = 0; h < 2; ++h) {
+      float sav[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t n = min(nbase + r, p.N - 1);
-      sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
-      bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+      for (int ii = 0; ii < 4; ++ii)
+        sav[ii] = p.sa_row ? p.sa[min(m0 + wm * 128 + (h * 4 + ii) * 16 + r16, p.M - 1)] : p.sa[0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
+        float sbv[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sbv[r] = p.sb_row ? p.sb[nbase + r] : p.sb[0];
+          bv[r] = p.bias ? (float)((const OutT*)p.bias)[nbase + r] : 0.f;
+        }
+        const int c = 2 * j + (q >> 1);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = h * 4 + ii, row = ii * 16 + r16;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sav[ii] * sbv[r] + bv[r];
+          *(uint2*)(stg + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 8 + pr;
+        const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
+        const int64_t m = m0 + wm * 128 + h * 64 + row;
+        if (m < p.M) stream_store16((OutT*)p.out + m * p.ldo + n0 + wn * 64 + pc * 8, v);
+      }
     }
+  } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t m = m0 + wm * 128 + i * 16 + r16;
-      if (m >= p.M) continue;
-      const float sav = p.sa_row ? p.sa[m] : p.sa[0];
-      OutT* o = (OutT*)p.out + m * p.ldo + nbase;
-      float v[4];
+    for (int j = 0; j < 4; ++j) {
+      const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
+      float sbv[4], bv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sav * sbv[r] + bv[r];
-      if (nbase + 3 < p.N && (p.ldo & 3) == 0) {
-        *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
-      } else {
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = min(nbase + r, p.N - 1);
+        sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+        bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (nbase + r < p.N) o[r] = (OutT)v[r];
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 16 + r16;
+        if (m >= p.M) continue;
+        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+        OutT* o = (OutT*)p.out + m * p.ldo + nbase;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sav * sbv[r] + bv[r];
+        if (nbase + 3 < p.N && (p.ldo & 3) == 0) {
+          *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nbase + r < p.N) o[r] = (OutT)v[r];
+        }
       }
     }
   }
+  // every wave is done with the LDS of this tile (staging reads included) before the next tile requests into it
+  __syncthreads();
+  cur = nxt;
+  }   // tiles of this workgroup
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // the last prefetch has landed: its register is free again
+#undef TL_FRAG
+#undef TL_XOFF
+#undef TL_WOFF
 }
 
 
@@ -1020,12 +1188,25 @@ static int tile_splits(int64_t M, int64_t N, int64_t K) {
   return S;
 }
 
+// workgroups of a persistent tile launch: one per CU (LDS and VGPRs allow one 8-wave workgroup per CU)
+static int tile_grid(int tiles) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  static const int persist = mi_tune("MI_GEMM_TILE_PERSIST", 1);
+  return persist && tiles > cus ? cus : tiles;
+}
+
 template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
   const int mblocks = (int)cdiv64(p.M, 256), nblocks = (int)cdiv64(p.N, 256);
   int S = tile_splits(p.M, p.N, p.K);
   if (S > 1 && (!workspace || workspace_bytes < (int64_t)S * p.M * p.N * (int64_t)sizeof(float))) S = 1;
-  fp8_gemm_tile_kernel<OutT><<<dim3((unsigned)(mblocks * nblocks), (unsigned)S), 512, 2 * 2 * 256 * 128, st>>>(
-      p, mblocks, nblocks, (float*)workspace, S);
+  // S == 1: persistent, one workgroup per CU walks its share of the tiles; split-K: one workgroup per (tile, split)
+  const unsigned gx = S == 1 ? (unsigned)tile_grid(mblocks * nblocks) : (unsigned)(mblocks * nblocks);
+  fp8_gemm_tile_kernel<OutT><<<dim3(gx, (unsigned)S), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, (float*)workspace, S);
   if (S > 1) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, (const float*)workspace, S);
@@ -1071,8 +1252,8 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
     }
     return;
   }
-  if (p.K % 128 == 0) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
-    launch_tile<OutT>(p, st, workspace, workspace_bytes);
+  if (p.K % 128 == 0 && p.lda < (1 << 24) && p.ldb < (1 << 24)) {  // prefill shapes: 256 x 256 LDS-tiled MFMA kernel
+    launch_tile<OutT>(p, st, workspace, workspace_bytes);             // (row pitches in its 24-bit offset multiplies)
     return;
   }
   const unsigned gx = (unsigned)cdiv64(p.N, 64);
@@ -1149,7 +1330,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
                                           void* q_out, const float* q_scale, int64_t M, int64_t I, int64_t K, int64_t lda,
                                           int64_t ldb, int dtype, void* stream) {
   const int64_t N = 2 * I;
-  if (M > 512 && K % 128 == 0 && I % 128 == 0 && lda % 16 == 0 && ldb % 16 == 0 &&
+  if (M > 512 && K % 128 == 0 && I % 128 == 0 && lda % 16 == 0 && ldb % 16 == 0 && lda < (1 << 24) && ldb < (1 << 24) &&
       !(((uintptr_t)a | (uintptr_t)b_nk) & 15) && !((uintptr_t)q_out & 3)) {
     // prefill: the 256 x 256 tile kernel with the same epilogue (a tile = 128 gate + 128 up rows of the weights)
     GemmParams p;
@@ -1159,9 +1340,9 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
     const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(I / 128);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MI_BF16)
-      fp8_gemm_tile_kernel<bf16_t, 1><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+      fp8_gemm_tile_kernel<bf16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
     else
-      fp8_gemm_tile_kernel<f16_t, 1><<<(unsigned)(mblocks * nblocks), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+      fp8_gemm_tile_kernel<f16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
     MI_CHECK_LAUNCH();
     return MI_OK;
   }

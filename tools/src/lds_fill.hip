@@ -15,6 +15,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+__device__ __forceinline__ const uint8_t* uniform_ptr(const void* ptr) {
+  const uint64_t v = (uint64_t)(uintptr_t)ptr;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 template <int MODE, int DEPTH>   // DEPTH = 64-KiB stages in flight (1 or 2)
 __global__ __launch_bounds__(512) void fill(const uint4* __restrict__ src, int iters, size_t region_vec, float* out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,6 +118,319 @@ __global__ __launch_bounds__(512) void fill_mix_half(const uint4* __restrict__ x
   if (acc == 1.2345f) out[0] = acc;
 }
 
+// mode 5: the prefill tile GEMM's traffic with the MFMAs removed -- per k-step a 256-row x 128-B slab of x and of w
+// (64 KiB), one stage in flight, workgroup -> tile by the kernel's XCD-aware 8 x 4 patches.  TILED = false: rows are K
+// bytes apart (the [rows][K] matrices as they are); TILED = true: every slab is one contiguous 32-KiB block
+// ([row-block][k-step][256][128 B]), the same bytes and the same sharing between workgroups.
+template <bool TILED, int SWZ = 0>   // SWZ: lane -> (row, slot) inside a piece: 0 linear, 1 slot ^ (row>>1 & 7), 2 slot + (row>>1) mod 8,
+                                     // 3 the tile kernel's 4-bit XOR over (row bit, slot), 4 slot ^ 4 * (row>>1 & 1)
+__global__ __launch_bounds__(512) void gemm_traffic(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, int mblocks,
+                                                    int nblocks, int K, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+  const int nwg = mblocks * nblocks, orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int GM = 8, per_group = GM * nblocks;
+  const int grp = tid / per_group, in_grp = tid % per_group;
+  const int first_m = grp * GM, gsz = min(mblocks - first_m, GM);
+  const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+  const int KT = K / 128;
+  float acc = 0.f;
+  auto issue = [&](int kt, int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave * 4 + i;              // rows 8 piece .. +7, lane -> row (lane >> 3), 16-B slot (lane & 7)
+      int row = piece * 8 + (lane >> 3), slot = lane & 7;
+      if (SWZ == 1) slot ^= (row >> 1) & 7;
+      if (SWZ == 2) slot = (slot + (row >> 1)) & 7;
+      if (SWZ == 4) slot ^= 4 * ((row >> 1) & 1);
+      if (SWZ == 3) {
+        const int line = piece * 4 + (lane >> 4), logical = (lane & 15) ^ (line & 15);
+        row = line * 2 + (logical >> 3);
+        slot = logical & 7;
+      }
+      const uint8_t *xs, *ws;
+      if (TILED) {
+        xs = x + (((size_t)mb * KT + kt) * 256 + row) * 128 + slot * 16;
+        ws = w + (((size_t)nb * KT + kt) * 256 + row) * 128 + slot * 16;
+      } else {
+        xs = x + ((size_t)mb * 256 + row) * K + (size_t)kt * 128 + slot * 16;
+        ws = w + ((size_t)nb * 256 + row) * K + (size_t)kt * 128 + slot * 16;
+      }
+      glds16(xs, lds_base + st * 65536 + piece * 1024);
+      glds16(ws, lds_base + st * 65536 + 32768 + piece * 1024);
+    }
+  };
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, st ^ 1);
+    acc += *(const float*)(smem + st * 65536 + ((lane * 67 + wave * 131 + kt) & 16383) * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (acc == 1.2345f) out[0] = acc;
+}
+
+// mode 6: the tile kernel's k-loop itself (DMA of the next stage, fragment reads, MFMAs, wait, barrier) with parts
+// switched off, and no epilogue: which part of the 2.3 us per k-step is what
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <bool DO_LDS, bool DO_MFMA, bool INTERLEAVE, int EPI = 0>   // EPI 1: the kernel's bf16 epilogue (8-byte stores)
+__global__ __launch_bounds__(512) void gemm_loop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, int mblocks,
+                                                 int nblocks, int K, float* out, uint16_t* __restrict__ obuf = nullptr,
+                                                 const float* __restrict__ sa = nullptr, const float* __restrict__ sb = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4, wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+  const int nwg = mblocks * nblocks, orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int GM = 8, per_group = GM * nblocks;
+  const int grp = tid / per_group, in_grp = tid % per_group;
+  const int first_m = grp * GM, gsz = min(mblocks - first_m, GM);
+  const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+  const int KT = K / 128;
+  const uint8_t* xp[4];
+  const uint8_t* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int line = piece * 4 + (lane >> 4), logical = (lane & 15) ^ (line & 15);
+    const int row = line * 2 + (logical >> 3), slot = logical & 7;
+    xp[i] = x + ((size_t)mb * 256 + row) * K + slot * 16;
+    wp[i] = w + ((size_t)nb * 256 + row) * K + slot * 16;
+  }
+#define PIECE(kt_, st_, i_)                                                                  \
+  {                                                                                          \
+    glds16(xp[i_] + (size_t)(kt_) * 128, lds_base + (st_) * 65536 + (wave * 4 + (i_)) * 1024);          \
+    glds16(wp[i_] + (size_t)(kt_) * 128, lds_base + (st_) * 65536 + 32768 + (wave * 4 + (i_)) * 1024);  \
+  }
+#define FRAG(base_, row_, slot_) \
+  (*(const uint4*)((base_) + ((row_) >> 1) * 256 + (((((row_) & 1) << 3) | (slot_)) ^ (((row_) >> 1) & 15)) * 16))
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float keep = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) PIECE(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int st = kt & 1;
+    const int ktn = min(kt + 1, KT - 1);
+    if (!INTERLEAVE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) PIECE(ktn, st ^ 1, i);
+    }
+    const char* xb = smem + st * 65536;
+    const char* wb = xb + 32768;
+    if (DO_LDS) {
+      i32x8 wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + r16;
+        const uint4 a0 = FRAG(wb, row, q), a1 = FRAG(wb, row, 4 + q);
+        wf[j] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + r16;
+        const uint4 b0 = FRAG(xb, row, q), b1 = FRAG(xb, row, 4 + q);
+        const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        if (INTERLEAVE && i < 4) PIECE(ktn, st ^ 1, i);
+        if (DO_MFMA) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        } else {
+          keep += __int_as_float(xf[0] ^ xf[7] ^ wf[i & 3][1]);
+        }
+      }
+    } else {
+      if (INTERLEAVE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PIECE(ktn, st ^ 1, i);
+      }
+      keep += *(const float*)(smem + st * 65536 + ((lane * 67 + wave * 131 + kt) & 16383) * 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (EPI == 1) {
+    const size_t N = (size_t)nblocks * 256;
+    const float sav = sa[0], sbv = sb[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t nbase = (size_t)nb * 256 + wn * 64 + j * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const size_t m = (size_t)mb * 256 + wm * 128 + i * 16 + r16;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sav * sbv;
+        uint32_t lo, hi;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+        *(uint2*)(obuf + m * N + nbase) = make_uint2(lo, hi);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (keep == 1.2345f) out[0] = keep;
+#undef PIECE
+#undef FRAG
+}
+
+// mode 7: PERSISTENT form of the tile kernel: one workgroup per CU walks its XCD's tiles; the first stage of the next
+// tile is requested during the last k-step, the bf16 tile leaves through LDS as whole 128-byte lines and the stores
+// drain under the next tile's first k-steps.
+template <int EPI>   // 0: no output, 2: staged full-line bf16 stores
+__global__ __launch_bounds__(512) void gemm_persist(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, int mblocks,
+                                                    int nblocks, int K, float* out, uint16_t* __restrict__ obuf,
+                                                    const float* __restrict__ sa, const float* __restrict__ sb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4, wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+  const int nwg = mblocks * nblocks, orig = blockIdx.x, G = gridDim.x;
+  const int xcd = orig & 7, slot = orig >> 3, gx = (G - xcd + 7) >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int start = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+  const int cnt = qd + (xcd < rm ? 1 : 0);
+  const int GM = 8, per_group = GM * nblocks;
+  const int KT = K / 128;
+  const size_t N = (size_t)nblocks * 256;
+  auto decode = [&](int li, int& mb, int& nb) {
+    const int tid = start + li;
+    const int grp = tid / per_group, in_grp = tid % per_group;
+    const int first_m = grp * GM, gsz = min(mblocks - first_m, GM);
+    mb = first_m + in_grp % gsz;
+    nb = in_grp / gsz;
+  };
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_base + wave * 4 * 1024);
+  uint32_t off[4];       // lane offsets inside a 256-row block (the same for x and w: both have K-byte rows)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int line = piece * 4 + (lane >> 4), logical = (lane & 15) ^ (line & 15);
+    const int row = line * 2 + (logical >> 3), sl = logical & 7;
+    off[i] = (uint32_t)(row * K + sl * 16);
+  }
+#define FRAG(base_, row_, slot_) \
+  (*(const uint4*)((base_) + ((row_) >> 1) * 256 + (((((row_) & 1) << 3) | (slot_)) ^ (((row_) >> 1) & 15)) * 16))
+  float keep = 0.f;
+  int step = 0;
+  bool first_issued = false;
+  for (int li = slot; li < cnt; li += gx) {
+    int mb, nb, mbn = 0, nbn = 0;
+    decode(li, mb, nb);
+    const bool has_next = li + gx < cnt;
+    if (has_next) decode(li + gx, mbn, nbn);
+    const uint8_t* xb0 = uniform_ptr(x + (size_t)mb * 256 * K);
+    const uint8_t* wb0 = uniform_ptr(w + (size_t)nb * 256 * K);
+    const uint8_t* xbn = uniform_ptr(x + (size_t)mbn * 256 * K);
+    const uint8_t* wbn = uniform_ptr(w + (size_t)nbn * 256 * K);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first_issued) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16_s(off[i], xb0, lds_piece + (step & 1) * 65536 + i * 1024);
+        glds16_s(off[i], wb0, lds_piece + (step & 1) * 65536 + 32768 + i * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    for (int kt = 0; kt < KT; ++kt, ++step) {
+      const int st = step & 1;
+      const bool last = kt + 1 == KT;
+      const uint8_t* xs = last ? xbn : xb0 + (size_t)(kt + 1) * 128;      // last k-step: the NEXT tile's first stage
+      const uint8_t* ws = last ? wbn : wb0 + (size_t)(kt + 1) * 128;
+      const char* xb = smem + st * 65536;
+      const char* wb = xb + 32768;
+      i32x8 wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + r16;
+        const uint4 a0 = FRAG(wb, row, q), a1 = FRAG(wb, row, 4 + q);
+        wf[j] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + r16;
+        const uint4 b0 = FRAG(xb, row, q), b1 = FRAG(xb, row, 4 + q);
+        const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        if (i < 4) {
+          glds16_s(off[i], xs, lds_piece + (st ^ 1) * 65536 + i * 1024);
+          glds16_s(off[i], ws, lds_piece + (st ^ 1) * 65536 + 32768 + i * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    first_issued = has_next;
+    if (EPI >= 2) {
+      // stage buffer `(step - 1) & 1` is free (the next tile's first stage is landing in the other one): 8 KiB per wave,
+      // two passes of 64 rows
+      char* stg = smem + ((step - 1) & 1) * 65536 + wave * 8192;
+      const float sav = sa[0], sbv = sb[0];
+      const int pr = lane >> 3, pc = lane & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 2 * j + (q >> 1);
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const int i = h * 4 + ii, row = ii * 16 + r16;
+            uint32_t lo, hi;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(acc[i][j][0] * sav * sbv), "v"(acc[i][j][1] * sav * sbv));
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(acc[i][j][2] * sav * sbv), "v"(acc[i][j][3] * sav * sbv));
+            *(uint2*)(stg + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = make_uint2(lo, hi);
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int row = ps * 8 + pr;
+          const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
+          const size_t m = (size_t)mb * 256 + wm * 128 + h * 64 + row;
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+          u32x4_t* dstp = (u32x4_t*)(obuf + m * N + (size_t)nb * 256 + wn * 64 + pc * 8);
+          if (EPI == 3) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, dstp);
+          else *dstp = u32x4_t{v.x, v.y, v.z, v.w};
+        }
+      }
+      __syncthreads();     // the staging reads are done: the buffer may take the next tile's second stage
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (keep == 1.2345f) out[0] = keep;
+#undef FRAG
+}
+
 int main() {
   const size_t region = 8u << 20;
   uint4* src; float* out;
@@ -144,6 +468,61 @@ int main() {
     runm("half stages x 32, ring 3", [&](int r) { fill_mix_half<3><<<256, 512, 3 * 32768>>>(src, WB(r), 32, out); });
     runm("half stages x 32, ring 4", [&](int r) { fill_mix_half<4><<<256, 512, 4 * 32768>>>(src, WB(r), 32, out); });
     runm("half stages x 32, ring 5", [&](int r) { fill_mix_half<5><<<256, 512, 5 * 32768>>>(src, WB(r), 32, out); });
+  }
+  {
+    const int M = 16384, N = 28672;
+    for (int K : {4096, 14336}) {
+      const int Nn = K == 4096 ? N : 4096;
+      uint8_t *x, *w;
+      CK(hipMalloc(&x, (size_t)M * K)); CK(hipMemset(x, 1, (size_t)M * K));
+      CK(hipMalloc(&w, (size_t)Nn * K)); CK(hipMemset(w, 2, (size_t)Nn * K));
+      const int mblocks = M / 256, nblocks = Nn / 256;
+      auto rung = [&](const char* name, auto kern) {
+        kern(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); kern(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double bytes = (double)mblocks * nblocks * (K / 128) * 65536;
+        printf("%-44s K=%5d N=%5d %8.3f ms  %7.1f GB/s total  %6.1f GB/s per CU\n", name, K, Nn, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 256);
+      };
+      rung("GEMM traffic, rows K bytes apart", [&] { gemm_traffic<false><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("GEMM traffic, slabs contiguous (tiled)", [&] { gemm_traffic<true><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("k-loop: DMA only", [&] { gemm_loop<false, false, false><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("k-loop: DMA + fragment reads", [&] { gemm_loop<true, false, false><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("k-loop: DMA + fragment reads + MFMA", [&] { gemm_loop<true, true, false><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("k-loop: same, DMA between MFMA groups", [&] { gemm_loop<true, true, true><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      {
+        uint16_t* ob; float* sc;
+        CK(hipMalloc(&ob, (size_t)M * Nn * 2)); CK(hipMalloc(&sc, 8)); CK(hipMemset(sc, 0, 8));
+        rung("persistent, no output", [&] { gemm_persist<0><<<256, 512, 131072>>>(x, w, mblocks, nblocks, K, out, ob, sc, sc + 1); });
+        rung("persistent, staged full-line bf16 stores", [&] { gemm_persist<2><<<256, 512, 131072>>>(x, w, mblocks, nblocks, K, out, ob, sc, sc + 1); });
+        rung("persistent, same with nontemporal stores", [&] { gemm_persist<3><<<256, 512, 131072>>>(x, w, mblocks, nblocks, K, out, ob, sc, sc + 1); });
+        {   // the same kernel over ROTATING weight buffers (no help from the 256-MB Infinity Cache), 3 x 4 launches
+          uint8_t* wr[4];
+          for (int r = 0; r < 4; ++r) { CK(hipMalloc(&wr[r], (size_t)Nn * K)); CK(hipMemset(wr[r], 2 + r, (size_t)Nn * K)); }
+          for (int r = 0; r < 4; ++r) gemm_persist<3><<<256, 512, 131072>>>(x, wr[r], mblocks, nblocks, K, out, ob, sc, sc + 1);
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0));
+          for (int rep = 0; rep < 3; ++rep)
+            for (int r = 0; r < 4; ++r) gemm_persist<3><<<256, 512, 131072>>>(x, wr[r], mblocks, nblocks, K, out, ob, sc, sc + 1);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 12;
+          printf("%-44s K=%5d N=%5d %8.3f ms  (%.0f TFLOP/s)\n", "persistent NT, 4 rotating weight buffers", K, Nn, ms, 2.0 * M * Nn * K / ms / 1e9);
+          CK(hipEventRecord(e0));
+          for (int rep = 0; rep < 12; ++rep) gemm_persist<3><<<256, 512, 131072>>>(x, wr[0], mblocks, nblocks, K, out, ob, sc, sc + 1);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 12;
+          printf("%-44s K=%5d N=%5d %8.3f ms  (%.0f TFLOP/s)\n", "persistent NT, one weight buffer, 12 launches", K, Nn, ms, 2.0 * M * Nn * K / ms / 1e9);
+          for (int r = 0; r < 4; ++r) CK(hipFree(wr[r]));
+        }
+        rung("k-loop + bf16 epilogue (8-byte stores)", [&] { gemm_loop<true, true, false, 1><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out, ob, sc, sc + 1); });
+        CK(hipFree(ob)); CK(hipFree(sc));
+      }
+      rung("rows K apart, slot ^ (row>>1 & 7)", [&] { gemm_traffic<false, 1><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("rows K apart, slot + (row>>1) mod 8", [&] { gemm_traffic<false, 2><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("rows K apart, the kernel's 4-bit XOR", [&] { gemm_traffic<false, 3><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      rung("rows K apart, 64-B halves swapped", [&] { gemm_traffic<false, 4><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out); });
+      CK(hipFree(x)); CK(hipFree(w));
+    }
   }
   return 0;
 }
