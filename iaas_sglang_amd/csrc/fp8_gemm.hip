@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
 static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8..15: tile-kernel group size override (tuning);
                              // bits 16+: tile-kernel L2 prefetch distance in k-steps (0 = off)
   static const int r = mi_tune("MI_GEMM_ROTATE", 1) | ((mi_tune("MI_GEMM_TILE_GROUP_M", 0) & 0xff) << 8) |
-                       (mi_tune("MI_GEMM_TILE_PF", 3) << 16);
+                       (mi_tune("MI_GEMM_TILE_PF", 2) << 16);
   return r;
 }
 // waves per workgroup: 8 (two per SIMD: one wave's DMA issue overlaps the other's MFMAs) unless
@@ -891,16 +891,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 
   const int PF = p.rotate >> 16;
   uint32_t pf_sink = 0;
+  const float sa0 = p.sa ? p.sa[0] : 1.f, sb0 = p.sb ? p.sb[0] : 1.f;     // per-tensor scales: read once, not per tile
   int step = 0;                 // k-steps done by this workgroup: the stage buffer of a k-step is step & 1
   bool first_issued = false;    // the current tile's first stage was requested during the previous tile's last k-step
   TileAddr cur, nxt;
   if (slot < xcnt) tile_addr(slot, cur);
   for (int li = slot; li < xcnt; li += gx) {
   const bool more = li + gx < xcnt;
-  // the next tile's first stage can land during this tile's epilogue unless the epilogue needs all of LDS (EPI) --
-  // otherwise the last k-step requests this tile's own first stage again into the free buffer (never read): the loop
-  // body stays one basic block
-  const bool ahead = more && EPI == 0;
+  // the next tile's first stage lands during this tile's epilogue (which only uses the other stage buffer); the last
+  // tile's last k-step requests its own first stage again (never read): the loop body stays one basic block
+  const bool ahead = more;
   if (more) tile_addr(li + gx, nxt);
   else nxt = cur;
   const int64_t m0 = cur.m0, n0 = cur.n0;
@@ -983,83 +983,97 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 
   // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
   if constexpr (EPI == 1) {
-    // the loop's last barrier is behind every wave: the stage buffers are free.  All waves: x = round_T(acc*sa*sb)
-    f32x4* xch = (f32x4*)smem;               // [4 up waves][32 tiles][64 lanes] f32x4 = 128 KiB
+    // Waves (wm, c) [gate] and (wm, c + 2) [up] hold the two factors of the same 128 x 64 outputs in the same
+    // registers.  Each finishes HALF of them: the gate wave rows i = 0..3 (it needs the partner's up values), the up
+    // wave rows i = 4..7 (it needs the partner's gate values) -- all 8 waves share the SiLU arithmetic.  The values
+    // travel through the free 64-KiB stage buffer in two rounds of 8 KiB per wave (2 i x 4 j fragments), so the other
+    // buffer can take the next tile's first stage meanwhile.  Bits as mi_silu_and_mul_fp8 on the unfused GEMM.
     const bool up = wn >= 2;
+    const int c64 = (wn & 1) * 64;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t col = n0 + (wn & 1) * 64 + j * 16 + 4 * q;          // output column (0 .. I)
+      const int64_t col = n0 + c64 + j * 16 + 4 * q;                    // output column (0 .. I)
       const int64_t nsrc = (up ? Ihalf : 0) + col;                      // weight row the scale belongs to
       float sbv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sbv[r] = p.sb_row ? p.sb[min(nsrc + r, p.N - 1)] : p.sb[0];
+      for (int r = 0; r < 4; ++r) sbv[r] = p.sb_row ? p.sb[min(nsrc + r, p.N - 1)] : sb0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int64_t m = min(m0 + wm * 128 + i * 16 + r16, p.M - 1);
-        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+        const float sav = p.sa_row ? p.sa[m] : sa0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = round_to<OutT>(acc[i][j][r] * sav * sbv[r]);
-        if (up) xch[((wm * 2 + (wn - 2)) * 32 + i * 4 + j) * 64 + lane] = acc[i][j];
       }
     }
-    __syncthreads();
-    // gate waves: the quantised words of their 128 x 64 outputs, in registers
-    uint32_t wq[8][4];
-    if (!up) {
-      const float qs = *epi.q_scale;
-      const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+    const float qs = *epi.q_scale;
+    const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+    f32x4* mine = (f32x4*)(free_buf + wave * 8192);           // [8 fragments][64 lanes]
+    const f32x4* theirs = (const f32x4*)(free_buf + (wave ^ 2) * 8192);
+    const int ib = up ? 4 : 0;                                // the rows this wave finishes: i = ib .. ib + 3
+    uint32_t wq[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int rd = 0; rd < 2; ++rd) {
+      // publish what the partner finishes in this round: its rows are (4 - ib) + 2 rd + {0, 1}
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 u = xch[((wm * 2 + wn) * 32 + i * 4 + j) * 64 + lane];
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // (4 - ib) + 2 rd + ii with a compile-time index on both sides of the select
+          const f32x4 v = up ? acc[2 * rd + ii][j] : acc[4 + 2 * rd + ii][j];
+          mine[(ii * 4 + j) * 64 + lane] = v;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 o2 = theirs[(ii * 4 + j) * 64 + lane];
+          const f32x4 own = up ? acc[4 + 2 * rd + ii][j] : acc[2 * rd + ii][j];
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float g = acc[i][j][r];
-            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+            const float g = up ? o2[r] : own[r], u = up ? own[r] : o2[r];
+            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u);
             o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
           }
           uint32_t w = 0;
           w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
           w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
-          wq[i][j] = w;
+          wq[2 * rd + ii][j] = w;
         }
+      __syncthreads();
     }
     if (n0 + 128 <= Ihalf && (Ihalf & 15) == 0 && ((uintptr_t)epi.q_out & 15) == 0) {
-      // full tiles leave as whole 128-byte lines (the tile's 128 fp8 columns of a row), staged per 128-row half in
-      // the exchange buffer once every gate wave has read its partner's values: [128 rows][128 B], 16-byte chunk c
-      // of row R at position c ^ (R & 7).  Straight from the MFMA layout it was 4-byte stores, 16 rows x 16 B each.
-      __syncthreads();
-      char* stg = smem + wm * 16384;
-      if (!up) {
+      // full tiles leave as whole 128-byte lines (the tile's 128 fp8 columns of a row), staged per 128-row half:
+      // [128 rows][128 B], 16-byte chunk c of row R at position c ^ (R & 7).  Straight from the MFMA layout it was
+      // 4-byte stores, 16 rows x 16 B per instruction.
+      char* stg = free_buf + wm * 16384;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int row = i * 16 + r16;
-            *(uint32_t*)(stg + row * 128 + (((wn * 4 + j) ^ (row & 7)) << 4) + q * 4) = wq[i][j];
-          }
-      }
+        for (int j = 0; j < 4; ++j) {
+          const int row = (ib + ii) * 16 + r16;
+          *(uint32_t*)(stg + row * 128 + ((((wn & 1) * 4 + j) ^ (row & 7)) << 4) + q * 4) = wq[ii][j];
+        }
       __syncthreads();
       const int pr = lane >> 3, pc = lane & 7;
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {       // the four waves of this half (gate and up) take 32 rows each
+      for (int ps = 0; ps < 4; ++ps) {       // the four waves of this half take 32 rows each
         const int row = wn * 32 + ps * 8 + pr;
         const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
         const int64_t m = m0 + wm * 128 + row;
         if (m < p.M) stream_store16(epi.q_out + m * Ihalf + n0 + pc * 16, v);
       }
-    } else if (!up) {
+    } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t col = n0 + wn * 64 + j * 16 + 4 * q;
+        const int64_t col = n0 + c64 + j * 16 + 4 * q;
         if (col >= Ihalf) continue;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int64_t m = m0 + wm * 128 + i * 16 + r16;
+        for (int ii = 0; ii < 4; ++ii) {
+          const int64_t m = m0 + wm * 128 + (ib + ii) * 16 + r16;
           if (m >= p.M) continue;
-          *(uint32_t*)(epi.q_out + m * Ihalf + col) = wq[i][j];
+          *(uint32_t*)(epi.q_out + m * Ihalf + col) = wq[ii][j];
         }
       }
     }
@@ -1097,14 +1111,14 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       float sav[4];
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
-        sav[ii] = p.sa_row ? p.sa[min(m0 + wm * 128 + (h * 4 + ii) * 16 + r16, p.M - 1)] : p.sa[0];
+        sav[ii] = p.sa_row ? p.sa[min(m0 + wm * 128 + (h * 4 + ii) * 16 + r16, p.M - 1)] : sa0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t nbase = n0 + wn * 64 + j * 16 + 4 * q;
         float sbv[4], bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sbv[r] = p.sb_row ? p.sb[nbase + r] : p.sb[0];
+          sbv[r] = p.sb_row ? p.sb[nbase + r] : sb0;
           bv[r] = p.bias ? (float)((const OutT*)p.bias)[nbase + r] : 0.f;
         }
         const int c = 2 * j + (q >> 1);
@@ -1133,14 +1147,14 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t n = min(nbase + r, p.N - 1);
-        sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+        sbv[r] = p.sb_row ? p.sb[n] : sb0;
         bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int64_t m = m0 + wm * 128 + i * 16 + r16;
         if (m >= p.M) continue;
-        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+        const float sav = p.sa_row ? p.sa[m] : sa0;
         OutT* o = (OutT*)p.out + m * p.ldo + nbase;
         float v[4];
 #pragma unroll
