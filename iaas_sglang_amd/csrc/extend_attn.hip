@@ -495,74 +495,128 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     if (has_next) X32_STAGE_LOAD(tile + 1);
     const char* kl = smem + st * STAGE;
     const char* vl = kl + TILE;
+    const int32_t tbase = tile * KT;
+    // A wave walks the four 32-key sub-tiles of the tile as a two-stage software pipeline, written out by hand: the
+    // in-order issue of one wave otherwise serialises QK^T (8 dependent MFMAs) -> max -> exp -> PV, and with two waves
+    // per SIMD nothing hides those latencies (measured: MFMA 18 % busy, VALU 25 %, LDS 13 %; two thirds of the wave
+    // cycles waiting).
+    //   stage 1 of sub-tile j:  QK^T MFMAs of sub-tile j + 1, one per step, each followed by the exp / row-sum / pack
+    //                           of two scores of sub-tile j
+    //   stage 2 of sub-tile j:  PV MFMAs of sub-tile j, one per step, each followed by the running max of two
+    //                           scores of sub-tile j + 1
+    // LDS fragments are requested four MFMAs ahead of their use.  A sub-tile no row of the wave can see is still
+    // computed (masked: p = 0) -- only whole invisible TILES are skipped; that costs at most three sub-tiles per wave.
+    // The interleave is expressed by source order only.  Pinning it with `__builtin_amdgcn_sched_barrier(0)` after
+    // every MFMA + chunk pair produced WRONG results on hipcc 7.2 (rows of S read by the mask / max before the last
+    // MFMA of the chain had written them: the hazard wait states were missing next to the barriers) -- do not add them.
+    // Measured 16 x 2048 causal: 1.31 -> 1.17 ms; 4 x 8192: 3.17 -> 2.94 ms.
+    if (wave_active && tbase < wave_keys) {
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      f32x16 sA, sB;
+      uint4 kq[4];
+      s16x4 vq_lo[4], vq_hi[4];
+      uint32_t pw[2][4];
+      float tmx, nmsafe;
+#define X32_MFMA(A_, B_, C_)                                                             \
+  if constexpr (__is_same(T, bf16_t)) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0); \
+  else C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
+#define X32_KREAD(sub_, kk_) (*(const uint4*)(kl + 256 * 32 * (sub_) + kofs[kk_]))
+#define X32_VREAD(sub_, s2_, db_)                                                                                       \
+  {                                                                                                                     \
+    vq_lo[db_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * (sub_) + 16 * (s2_)) + vlo[db_])); \
+    vq_hi[db_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * (sub_) + 16 * (s2_)) + vhi[db_])); \
+  }
+      // mask (diagonal / tail sub-tiles only), row max over the 32 keys, deferred rescale decision for sub-tile sub_
+#define X32_MASK(sub_, S_)                                                                       \
+  {                                                                                              \
+    const int32_t kb_ = tbase + 32 * (sub_);                                                     \
+    if (!(kb_ + 31 < n_keys && (!causal || kb_ + 31 <= prefix + tok0))) {                        \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                           \
+        const int32_t kp = kb_ + (i & 3) + 8 * (i >> 2) + 4 * h;                                 \
+        const bool ok = kp < n_keys && (!causal || kp <= q_pos);                                 \
+        S_[i] = ok ? S_[i] : -INFINITY;                                                          \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#define X32_DECIDE()                                                                             \
+  {                                                                                              \
+    float tm_ = fmaxf(tmx, __shfl_xor(tmx, 32)) * p.scale_log2;   /* scale > 0: max(c x) = c max(x) */ \
+    if (__any(tm_ > m + 8.0f)) {   /* deferred rescale, decided before this sub-tile's P exists */ \
+      const float mn = fmaxf(m, tm_);                                                            \
+      const float mns = (mn == -INFINITY) ? 0.f : mn;                                            \
+      const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mns);                           \
+      m = mn;                                                                                    \
+      lsum *= alpha;                                                                             \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db)                                           \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[db][i] *= alpha;                      \
+    }                                                                                            \
+    nmsafe = (m == -INFINITY) ? 0.f : -m;                                                        \
+  }
+      // exp, row sum and pack of scores 2c, 2c + 1 of S_ (c = 0..7)
+#define X32_EXP(S_, c_)                                                                          \
+  {                                                                                              \
+    const float p0 = fast_exp2(fmaf(S_[2 * (c_)], p.scale_log2, nmsafe));                        \
+    const float p1 = fast_exp2(fmaf(S_[2 * (c_) + 1], p.scale_log2, nmsafe));                    \
+    lsum += p0 + p1;                                                                             \
+    pw[(c_) >> 2][(c_) & 3] = pack2_fast<T>(p0, p1);                                             \
+  }
+      // one pipelined sub-tile: CUR_ holds S of sub-tile sub_ (masked, its max decided), NXT_ receives sub-tile sub_ + 1
+#define X32_STEP(sub_, CUR_, NXT_)                                                               \
+  {                                                                                              \
+    constexpr bool more_ = (sub_) + 1 < KT / 32;                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                           \
+      if constexpr (more_) {                                                                     \
+        const vec8 kf_ = __builtin_bit_cast(vec8, kq[kk & 3]);                                   \
+        X32_MFMA(kf_, qf[kk], NXT_);                                                             \
+        if (kk + 4 < 8) kq[kk & 3] = X32_KREAD((sub_) + 1, kk + 4);                              \
+      }                                                                                          \
+      if (kk >= 4) X32_VREAD(sub_, 0, kk - 4);                                                   \
+      X32_EXP(CUR_, kk);                                                                         \
+    }                                                                                            \
+    if constexpr (more_) X32_MASK((sub_) + 1, NXT_);                                             \
+    tmx = -INFINITY;                                                                             \
+    _Pragma("unroll") for (int n = 0; n < 8; ++n) {                                              \
+      const vec8 pf_ = __builtin_bit_cast(vec8, u32x4{pw[n >> 2][0], pw[n >> 2][1], pw[n >> 2][2], pw[n >> 2][3]}); \
+      const s16x8 both_ = __builtin_shufflevector(vq_lo[n & 3], vq_hi[n & 3], 0, 1, 2, 3, 4, 5, 6, 7); \
+      X32_MFMA(__builtin_bit_cast(vec8, both_), pf_, acc[n & 3]);                                \
+      if (n < 4) X32_VREAD(sub_, 1, n)                                                           \
+      else if constexpr ((sub_) + 2 < KT / 32) kq[n & 3] = X32_KREAD((sub_) + 2, n & 3);         \
+      if constexpr (more_) tmx = fmaxf(tmx, fmaxf(NXT_[2 * n], NXT_[2 * n + 1]));                \
+    }                                                                                            \
+    if constexpr (more_) X32_DECIDE();                                                           \
+  }
+      // ---- prologue: S of sub-tile 0 (plain), its mask / max / decision; K fragments of sub-tile 1
 #pragma unroll
-    for (int sub = 0; sub < KT / 32; ++sub) {
-      const int32_t kbase = tile * KT + 32 * sub;
-      if (wave_active && kbase < wave_keys) {
-        // ---- S^T = K . Q^T
-        f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // folds into the first MFMA's C = 0
+      for (int i = 0; i < 16; ++i) { sA[i] = 0.f; sB[i] = 0.f; }
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const vec8 kf = __builtin_bit_cast(vec8, *(const uint4*)(kl + 256 * 32 * sub + kofs[kk]));
-          if constexpr (__is_same(T, bf16_t))
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
-          else
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s, 0, 0, 0);
-        }
-        // ---- scale, mask, online softmax: register i of lane half h is key kbase + (i & 3) + 8 (i >> 2) + 4 h
-        const bool all_visible = kbase + 31 < n_keys && (!causal || kbase + 31 <= prefix + tok0);
-        // the raw logits stay in s; the softmax scale rides in the exponent's fma (one VALU per score instead of two)
-        if (!all_visible) {
+      for (int kk = 0; kk < 4; ++kk) kq[kk] = X32_KREAD(0, kk);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int32_t kp = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const bool ok = kp < n_keys && (!causal || kp <= q_pos);
-            s[i] = ok ? s[i] : -INFINITY;
-          }
-        }
-        float tm = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-#pragma unroll
-        for (int i = 4; i < 16; i += 4) tm = fmaxf(tm, fmaxf(fmaxf(s[i], s[i + 1]), fmaxf(s[i + 2], s[i + 3])));
-        tm = fmaxf(tm, __shfl_xor(tm, 32)) * p.scale_log2;     // scale > 0: max(c x) = c max(x)
-        if (__any(tm > m + 8.0f)) {      // deferred rescale, decided before this sub-tile's P exists
-          const float mn = fmaxf(m, tm);
-          const float mns = (mn == -INFINITY) ? 0.f : mn;
-          const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mns);
-          m = mn;
-          lsum *= alpha;
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[db][i] *= alpha;
-        }
-        const float nmsafe = (m == -INFINITY) ? 0.f : -m;
-        uint32_t pw[2][4];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const float p0 = fast_exp2(fmaf(s[8 * s2 + 2 * jj], p.scale_log2, nmsafe));
-            const float p1 = fast_exp2(fmaf(s[8 * s2 + 2 * jj + 1], p.scale_log2, nmsafe));
-            lsum += p0 + p1;
-            pw[s2][jj] = pack2_fast<T>(p0, p1);
-          }
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const vec8 pf = __builtin_bit_cast(vec8, u32x4{pw[s2][0], pw[s2][1], pw[s2][2], pw[s2][3]});
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * sub + 16 * s2) + vlo[db]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vl + 256 * (32 * sub + 16 * s2) + vhi[db]));
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            if constexpr (__is_same(T, bf16_t))
-              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec8, both), pf, acc[db], 0, 0, 0);
-            else
-              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vec8, both), pf, acc[db], 0, 0, 0);
-          }
-        }
+      for (int kk = 0; kk < 8; ++kk) {
+        const vec8 kf = __builtin_bit_cast(vec8, kq[kk & 3]);
+        X32_MFMA(kf, qf[kk], sA);
+        if (kk + 4 < 8) kq[kk & 3] = X32_KREAD(0, kk + 4);
+        else kq[kk & 3] = X32_KREAD(1, kk & 3);
       }
+      X32_MASK(0, sA);
+      tmx = fmaxf(fmaxf(sA[0], sA[1]), fmaxf(sA[2], sA[3]));
+#pragma unroll
+      for (int i = 4; i < 16; i += 4) tmx = fmaxf(tmx, fmaxf(fmaxf(sA[i], sA[i + 1]), fmaxf(sA[i + 2], sA[i + 3])));
+      X32_DECIDE();
+      X32_STEP(0, sA, sB);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sA[i] = 0.f;
+      X32_STEP(1, sB, sA);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sB[i] = 0.f;
+      X32_STEP(2, sA, sB);
+      X32_STEP(3, sB, sA);
+#undef X32_MFMA
+#undef X32_KREAD
+#undef X32_VREAD
+#undef X32_MASK
+#undef X32_DECIDE
+#undef X32_EXP
+#undef X32_STEP
     }
     if (has_next) X32_STAGE_WRITE(st ^ 1);
     __syncthreads();
