@@ -79,7 +79,8 @@ def test_gemm_rope_kvwrite_bit_identical(M, Hq, Hkv, D, K, dtype):
 
 @pytest.mark.parametrize("M,I,K", [(128, 14336, 4096), (77, 14336, 4096), (128, 1792, 4096), (3, 512, 256), (16, 64, 128),
                                    (128, 1000 * 8, 512),
-                                   (2048, 14336, 1024), (700, 1792, 4096), (513, 128, 128)])   # prefill: tile-kernel epilogue
+                                   (2048, 14336, 1024), (700, 1792, 4096), (513, 128, 128),    # prefill: tile-kernel epilogue
+                                   (4300, 2176, 256)])      # 17 x 17 tiles on 256 CUs: persistent loop, ragged last row block
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_silu_mul_fp8_bit_identical(M, I, K, dtype):
     """Covers both routes: the in-kernel epilogue (N large, no split-K: 14336) and the slab consumer."""

@@ -78,7 +78,10 @@ def test_fp8_gemm_golden(golden_quant, name):
                                    # C5 per rank (Llama-3-70B, TP=8, batch 256): qkv, o, gate_up, down
                                    (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584),
                                    (136, 4096, 4096), (500, 4096, 2048),           # chunks of rows: 136, 256 + 244
-                                   (1100, 4096, 14336), (2000, 1024, 4096)])       # tile kernel with split-K slabs (S = 4, 2..4)
+                                   (1100, 4096, 14336), (2000, 1024, 4096),        # tile kernel with split-K slabs (S = 4, 2..4)
+                                   # more tiles than CUs: the persistent tile loop (next tile's first stage requested in
+                                   # the last k-step, LDS-staged line stores) with ragged last row / column blocks
+                                   (4300, 4304, 256), (8192, 6144, 384)])
 @pytest.mark.parametrize("modes", ["tt", "rr", "rt"])
 def test_fp8_gemm_random(M, N, K, modes):
     o_ = ops()
