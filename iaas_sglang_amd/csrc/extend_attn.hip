@@ -625,17 +625,31 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
 #undef X32_STAGE_LOAD
 #undef X32_STAGE_WRITE
 
-  // ---- epilogue: lane holds O[row r][d = 32 db + (i & 3) + 8 (i >> 2) + 4 h]
+  // ---- epilogue: lane holds O[row r][d = 32 db + (i & 3) + 8 (i >> 2) + 4 h].  The wave's 32 x 128 outputs go through
+  // 8 KiB of the (free) stage buffers and leave as whole 256-byte head rows, 4 rows per non-temporal store instruction;
+  // straight from the MFMA layout it was 16 stores of 32 rows x 16 B each (partial lines: the pattern that cost the
+  // tile GEMM a third of its time).  LDS image: [32 rows][256 B], 16-byte chunk c of row R at position c ^ (R & 15).
   lsum += __shfl_xor(lsum, 32);
-  if (wave_active && tok0 + r < ext_len) {
+  if (wave_active) {
     const float inv = 1.f / lsum;
-    T* op = (T*)p.o + (int64_t)(q_start + tok0 + r) * p.stride_o_tok + (int64_t)head * D + 4 * h;
+    char* stg = smem + wave * 8192;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *(uint2*)(op + 32 * db + 8 * g) = make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
-                                                     pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
+        *(uint2*)(stg + 256 * r + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) =
+            make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
+                       pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
+    const int pr = lane >> 4, pc = lane & 15;
+    typedef __attribute__((ext_vector_type(4))) uint32_t st_u32x4;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int row = ps * 4 + pr;
+      const uint4 v = *(const uint4*)(stg + 256 * row + ((pc ^ (row & 15)) << 4));
+      if (tok0 + row < ext_len)
+        __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w},
+                                    (st_u32x4*)((T*)p.o + (int64_t)(q_start + tok0 + row) * p.stride_o_tok + (int64_t)head * D + 8 * pc));
+    }
   }
 }
 
@@ -662,6 +676,7 @@ static bool try_launch_extend32(const ExtendParams& p, int64_t batch, int64_t ma
   static const int enable = mi_tune("MI_EXTEND_32", 1);
   if (!enable || max_extend_len < 64 || p.custom_mask || p.sliding_window > 0 || p.logit_cap > 0.f || p.num_splits != 1)
     return false;
+  if (p.stride_o_tok % 8 != 0 || ((uintptr_t)p.o & 15) != 0) return false;     // its 16-byte output stores
   const int g = p.group;
 #define X32(HGV, NWV)                                                                                                     \
   {                                                                                                                       \
