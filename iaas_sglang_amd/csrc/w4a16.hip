@@ -495,6 +495,43 @@ __global__ __launch_bounds__(512) void w4a16_tile_kernel(const W4Params p, int m
   }
 
   // ---- epilogue: lane holds out[m = m0 + 16 t + r16][n = n0 + 16 j + 4 q + r]
+  // Full tiles without split-K: two neighbouring waves (64 + 64 bytes of every row) stage their outputs in 32 KiB of the
+  // now free rings -- [256 rows][128 B], 16-byte chunk c of row R at position c ^ (R & 7) -- and the pair writes whole
+  // 128-byte lines, 8 rows per non-temporal store (the MFMA layout gives 8-byte stores, 16 rows x 32 B per instruction:
+  // partial lines, which cost fp8_gemm_tile_kernel a third of its time before the same change).
+  const bool staged = S == 1 && tile_ok[0] && tile_ok[1] && ((int64_t)nb * BN + BN <= p.N) && (p.ldo & 7) == 0 &&
+                      ((uintptr_t)p.out & 15) == 0;     // uniform over the workgroup (nb, not the wave's n0)
+  if (staged) {
+    __syncthreads();                                    // every wave is done with the rings
+    char* stg = smem + (wave >> 1) * 32768;
+    const int half = wave & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t nbase = n0 + j * 16 + 4 * q;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = p.bias ? (float)((const T*)p.bias)[nbase + r] : 0.f;
+      const int c = half * 4 + j * 2 + (q >> 1);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = t * 16 + r16;
+        *(uint2*)(stg + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) =
+            make_uint2(pack2<T>(acc[t][j][0] + bv[0], acc[t][j][1] + bv[1]), pack2<T>(acc[t][j][2] + bv[2], acc[t][j][3] + bv[3]));
+      }
+    }
+    __syncthreads();
+    const int pr = lane >> 3, pc = lane & 7;
+    typedef __attribute__((ext_vector_type(4))) uint32_t st_u32x4;
+    const int64_t ncol = (int64_t)nb * BN + (wave >> 1) * 64 + pc * 8;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      const int row = half * 128 + ps * 8 + pr;
+      const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
+      const int64_t m = m0 + row;
+      if (m < p.M) __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w}, (st_u32x4*)((T*)p.out + m * p.ldo + ncol));
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if (!tile_ok[j]) continue;
