@@ -63,9 +63,17 @@ template <> struct Elem<f16_t> {
 };
 
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  asm volatile("" : "+v"(a), "+v"(b));   // fp32 values first, then ONE conversion each (see round_to below)
-  T x = (T)a, y = (T)b;
-  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+  if constexpr (__is_same(T, bf16_t)) {
+    // one v_cvt_pk_bf16_f32 for the pair: the instruction hipcc itself uses for each `(bf16)x` (round to nearest even),
+    // without the two single-lane converts + shift + or around it (5 instructions per pair in the GEMM epilogues)
+    uint32_t r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    asm volatile("" : "+v"(a), "+v"(b));   // fp32 values first, then ONE conversion each (see round_to below)
+    T x = (T)a, y = (T)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+  }
 }
 
 // fp32 -> T -> fp32 with the fp32 value materialised first: without the (empty) asm hipcc folds a preceding
