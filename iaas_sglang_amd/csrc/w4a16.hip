@@ -215,12 +215,17 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const W4Params p) {
 // Decode-shaped fused dequant GEMM (M <= 128, no act-order): same structure as fp8_gemm_xs_kernel.
 //   workgroup (nb, sp) = NWV waves = NWV 16-column weight tiles x a range of 128-element k-phases;
 //   per phase the activation block [M x 256 B] (fp16/bf16) and each wave's packed int4 block (one
-//   1-KiB native tile = 16 n x 128 k) go global -> LDS by inline-asm LDS-DMA into a 2-stage ring while
-//   the previous phase computes; the (scale, zero) words of the workgroup's whole k-range are staged
+//   1-KiB native tile = 16 n x 128 k) go global -> LDS by inline-asm LDS-DMA into a ring of R stages, R - 1 phases
+//   ahead, with counted vmcnt waits (every wave issues the same number of pieces per stage); with two stages and a
+//   full drain per phase every phase exposed most of a DMA latency (16 phases x ~1.2 us = the 22 us of the qkv
+//   shape at M = 64); the (scale, zero) words of the workgroup's whole k-range are staged
 //   once; x rows are unpadded with the 16-byte slot XOR-swizzled by (row & 15) on the source side.
 //   Per phase and wave: 1 ds_read_b128 of packed weights -> 4 dequantised MFMA fragments (exact
 //   (w - z) * s), 4 x MT MFMA 16x16x32.  Split-K partials go to fp32 slabs (w4_reduce_kernel).
 // Bound: HBM (N*K/2 bytes of weights read once) + per-CU ingest of the activation block.
+// ring depth of w4a16_xs_kernel: 4 stages (3 phases ahead) while R * stage + 16 KiB of zs fits the 160 KiB of LDS
+static constexpr int w4_xs_ring(int mt) { return mt >= 8 ? 3 : 4; }
+
 template <typename T, int MT, int NWV>
 __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, float* __restrict__ slab, int S,
                                                             int phases_per_wg) {
@@ -230,8 +235,12 @@ __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, fl
   constexpr int XBYTES = ROWS * PW;
   constexpr int STAGE = XBYTES + NWV * 1024;         // + one packed weight tile per wave
   constexpr int MAXPH = 32;                          // zs staging capacity (phases per workgroup)
+  constexpr int R = w4_xs_ring(MT);                  // ring stages (LDS: R * STAGE + 16 KiB of zs)
+  constexpr int LA = R - 1;                          // phases requested ahead
+  constexpr int XP = (ROWS / 4 + NWV - 1) / NWV;     // x pieces per wave and stage (clamped duplicates when ROWS / 4 < NWV)
+  constexpr int OPS = 1 + XP;                        // vmcnt entries per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* zs_lds = (uint32_t*)(smem + 2 * STAGE);  // [NWV][MAXPH][16]
+  uint32_t* zs_lds = (uint32_t*)(smem + R * STAGE);  // [NWV][MAXPH][16]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int64_t nt = (int64_t)blockIdx.x * NWV + wave;
@@ -260,14 +269,13 @@ __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, fl
 #define W4_STAGE(ph_, st_)                                                                             \
   {                                                                                                    \
     glds16(wq + (int64_t)(ph_) * 64, lds_base + (st_) * STAGE + XBYTES + wave * 1024);                 \
-    _Pragma("unroll") for (int i = 0; i < (ROWS / 4 + NWV - 1) / NWV; ++i) {                           \
-      const int rr_ = (i * NWV + wave) * 4;                                                            \
-      if (rr_ < ROWS) {                                                                                \
-        const int row_ = rr_ + drow;                                                                   \
-        const int ss_ = dslot ^ (row_ & 15);                                                           \
-        glds16((const T*)p.x + min((int64_t)row_, p.M - 1) * p.ldx + (int64_t)(ph_) * 128 + ss_ * 8,   \
-               lds_base + (st_) * STAGE + rr_ * PW);                                                   \
-      }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
+      /* a wave past the last piece re-requests the last one (same bytes, same place): every wave has OPS entries */ \
+      const int rr_ = min((i * NWV + wave) * 4, ROWS - 4);                                             \
+      const int row_ = rr_ + drow;                                                                     \
+      const int ss_ = dslot ^ (row_ & 15);                                                             \
+      glds16((const T*)p.x + min((int64_t)row_, p.M - 1) * p.ldx + (int64_t)(ph_) * 128 + ss_ * 8,     \
+             lds_base + (st_) * STAGE + rr_ * PW);                                                     \
     }                                                                                                  \
   }
 #define W4_MMA(ph_, st_)                                                                               \
@@ -285,24 +293,29 @@ __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, fl
       }                                                                                                \
     }                                                                                                  \
   }
-#define W4_WAIT()                                       \
-  {                                                     \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
-    __syncthreads();                                    \
-  }
+  // issue order: stages 0 .. LA-1 | iteration i: [wait stage i] barrier, request stage i + LA (into the slot stage
+  // i - 1 used: every wave is past it), compute stage i.  Younger than stage i at its wait: min(LA - 1, n - 1 - i) stages.
   if (ph0 < ph1) {
-    W4_STAGE(ph0, 0);
-    W4_WAIT();
-    for (int64_t ph = ph0; ph < ph1; ++ph) {
-      const int st = (int)((ph - ph0) & 1);
-      if (ph + 1 < ph1) W4_STAGE(ph + 1, st ^ 1);
-      W4_MMA(ph, st);
-      W4_WAIT();
+    const int n = (int)(ph1 - ph0);
+#pragma unroll
+    for (int a = 0; a < LA; ++a) {
+      const int64_t ph_a = ph0 + a;
+      if (a < n) W4_STAGE(ph_a, a);
+    }
+    for (int it = 0; it < n; ++it) {       // (not `i`: the macros have loops of their own over that name)
+      const int y = min(LA - 1, n - 1 - it);
+      if (y >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+      else if (y == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int64_t ph_req = ph0 + it + LA, ph_now = ph0 + it;
+      const int st_req = (it + LA) % R, st_now = it % R;
+      if (it + LA < n) W4_STAGE(ph_req, st_req);
+      W4_MMA(ph_now, st_now);
     }
   }
 #undef W4_STAGE
 #undef W4_MMA
-#undef W4_WAIT
   if (!tile_ok) return;
 
   const int64_t nb = n0 + 4 * q;
@@ -604,7 +617,7 @@ extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K
 template <typename T, int MT>
 static void launch_w4_xs(const W4Params& p, float* slab, int S, int ppw, hipStream_t st) {
   constexpr int NWV = 8;
-  const size_t lds = (size_t)2 * (MT * 16 * 256 + NWV * 1024) + (size_t)NWV * 32 * 16 * 4;
+  const size_t lds = (size_t)w4_xs_ring(MT) * (MT * 16 * 256 + NWV * 1024) + (size_t)NWV * 32 * 16 * 4;
   dim3 grid((unsigned)cdiv64(p.N, 16 * NWV), (unsigned)S);
   w4a16_xs_kernel<T, MT, NWV><<<grid, NWV * 64, lds, st>>>(p, slab, S, ppw);
   if (S > 1) w4_reduce_kernel<T><<<(unsigned)cdiv64(p.M * (p.N / 4), 256), 256, 0, st>>>(p, slab, S);
