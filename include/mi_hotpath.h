@@ -124,7 +124,8 @@ int64_t mi_decode_attn_workspace_bytes(int64_t batch, int64_t num_q_heads, int64
 
 /* Split-KV token (decode) attention over a paged KV pool, one query token per request.
  *   q [B,Hq,D] (stride_q_tok elements between tokens, heads contiguous D apart)
- *   k_buf/v_buf [slots,Hkv,D] (stride_*_slot elements between slots, heads D apart)
+ *   k_buf/v_buf [slots,Hkv,D] (stride_*_slot elements between slots, heads D apart; 0 < stride < 2^31:
+ *   slot index x stride is one 32 x 32 -> 64-bit multiply per row address)
  *   o [B,Hq,D] ; kv_indptr int32 [B+1] ; kv_indices int32 [kv_indptr[B]]
  *   o[b,h] = softmax_j(sm_scale * q[b,h].k_buf[kv_indices[kv_indptr[b]+j], h/group]) . v_buf[...]
  *   logit_cap > 0 applies cap*tanh(x/cap) to the scaled logits.
