@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_reduce_kernel(const GemmParams p
 static int gemm_rotate() {   // bit 0: k rotation (skinny kernel); bits 8..15: tile-kernel group size override (tuning);
                              // bits 16+: tile-kernel L2 prefetch distance in k-steps (0 = off)
   static const int r = mi_tune("MI_GEMM_ROTATE", 1) | ((mi_tune("MI_GEMM_TILE_GROUP_M", 0) & 0xff) << 8) |
-                       (mi_tune("MI_GEMM_TILE_PF", 2) << 16);
+                       (mi_tune("MI_GEMM_TILE_PF", 3) << 16);
   return r;
 }
 // waves per workgroup: 8 (two per SIMD: one wave's DMA issue overlaps the other's MFMAs) unless
@@ -815,7 +815,14 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
                                                             const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
   constexpr int BM = 256, BN = 256, BK = 128;
   constexpr int TILE = BM * BK;            // 32 KiB per operand per stage
-  constexpr int STAGE = 2 * TILE;          // x tile then w tile
+  // SPLIT ring over all 160 KiB of LDS: two activation stages (requested one k-step ahead) at [0, 64 KiB), THREE weight
+  // stages (requested TWO k-steps ahead) behind them.  The weights are what comes from HBM; the activation block is
+  // re-read by every n-block and sits in L2 / the Infinity Cache.  With one stage ahead for both, every k-step exposed
+  // the HBM latency of its weight lines: 1.50 ms for 16384 x 28672 x 4096 with fresh weights against 1.21 ms with the
+  // weights left in the Infinity Cache by the previous launch (probe tools/src/lds_fill.hip); with the weights two
+  // k-steps ahead the same probe runs fresh weights in 1.23 ms (and 16384 x 4096 x 14336 in 0.57 instead of 0.72 ms).
+#define TL_XST(s_) ((uint32_t)((s_) & 1) * (uint32_t)TILE)
+#define TL_WST(s_) ((uint32_t)(2 * TILE) + (uint32_t)((s_) % 3) * (uint32_t)TILE)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   const bool more = li + gx < xcnt;
   // the next tile's first stage lands during this tile's epilogue (which only uses the other stage buffer); the last
   // tile's last k-step requests its own first stage again (never read): the loop body stays one basic block
-  const bool ahead = more;
+  const bool ahead = more && KT - kt0 >= 2;     // (a one-step k range cannot request two steps ahead across tiles)
   if (more) tile_addr(li + gx, nxt);
   else nxt = cur;
   const int64_t m0 = cur.m0, n0 = cur.n0;
@@ -933,24 +940,29 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   if (!first_issued) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16_s(TL_XOFF(cur, i), cur.xblk + kt0 * BK, lds_piece + (step & 1) * STAGE + i * 1024);
-      glds16_s(TL_WOFF(cur, i), cur.wblk + kt0 * BK, lds_piece + (step & 1) * STAGE + TILE + i * 1024);
+      glds16_s(TL_XOFF(cur, i), cur.xblk + kt0 * BK, lds_piece + TL_XST(step) + i * 1024);
+      glds16_s(TL_WOFF(cur, i), cur.wblk + kt0 * BK, lds_piece + TL_WST(step) + i * 1024);
+      glds16_s(TL_WOFF(cur, i), cur.wblk + min(kt0 + 1, KT - 1) * BK, lds_piece + TL_WST(step + 1) + i * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   for (int64_t kt = kt0; kt < KT; ++kt, ++step) {
-    const int buf = step & 1;
-    // the next stage is requested piece by piece BETWEEN the first MFMA groups: both waves of a SIMD leave the barrier
+    // the requests are placed piece by piece BETWEEN the first MFMA groups: both waves of a SIMD leave the barrier
     // together, and with all eight requests up front they spent ~0.3 us issuing DMAs side by side before the first
-    // MFMA -- now one wave's requests run under the other's (and its own) MFMAs.
-    const bool last = kt + 1 == KT, from_next = last && ahead;
-    const int64_t kn = last ? kt0 : kt + 1;
-    const uint8_t* xs = (from_next ? nxt.xblk : cur.xblk) + kn * BK;
-    const uint8_t* ws = (from_next ? nxt.wblk : cur.wblk) + kn * BK;
-    const int xcl = from_next ? nxt.xclamp : cur.xclamp, wcl = from_next ? nxt.wclamp : cur.wclamp;
-    const char* xb = smem + buf * STAGE;
-    const char* wb = xb + TILE;
+    // MFMA -- now one wave's requests run under the other's (and its own) MFMAs.  A wave requests its 4 activation
+    // pieces of k-step kt + 1 FIRST, then its 4 weight pieces of k-step kt + 2: the wait at the end of the k-step
+    // leaves those 4 (and the prefetch) in flight.  Past the end of the tile the requests go to the next tile's first
+    // k-steps (`ahead`), or repeat this tile's (never read): the loop body stays one basic block.
+    const bool xnext = kt + 1 >= KT, wnext = kt + 2 >= KT;
+    const int64_t kx = xnext ? kt0 : kt + 1;
+    const int64_t kw = wnext ? min(kt0 + (kt + 2 - KT), KT - 1) : kt + 2;
+    const uint8_t* xs = ((xnext && ahead) ? nxt.xblk : cur.xblk) + kx * BK;
+    const uint8_t* ws = ((wnext && ahead) ? nxt.wblk : cur.wblk) + kw * BK;
+    const int xcl = (xnext && ahead) ? nxt.xclamp : cur.xclamp, wcl = (wnext && ahead) ? nxt.wclamp : cur.wclamp;
+    const uint32_t xdst = lds_piece + TL_XST(step + 1), wdst = lds_piece + TL_WST(step + 2);
+    const char* xb = smem + TL_XST(step);
+    const char* wb = smem + TL_WST(step);
     i32x8 wf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -963,9 +975,12 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       const int row = wm * 128 + i * 16 + r16;
       const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
       const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-      if (i < 4) {
-        glds16_s(__umul24((uint32_t)min(prow[i], xcl), lda32) + (uint32_t)pslot[i], xs, lds_piece + (buf ^ 1) * STAGE + i * 1024);
-        glds16_s(__umul24((uint32_t)min(prow[i], wcl), ldb32) + (uint32_t)pslot[i], ws, lds_piece + (buf ^ 1) * STAGE + TILE + i * 1024);
+      if (i < 2) {
+        glds16_s(__umul24((uint32_t)min(prow[2 * i], xcl), lda32) + (uint32_t)pslot[2 * i], xs, xdst + (2 * i) * 1024);
+        glds16_s(__umul24((uint32_t)min(prow[2 * i + 1], xcl), lda32) + (uint32_t)pslot[2 * i + 1], xs, xdst + (2 * i + 1) * 1024);
+      } else if (i < 4) {
+        glds16_s(__umul24((uint32_t)min(prow[2 * i - 4], wcl), ldb32) + (uint32_t)pslot[2 * i - 4], ws, wdst + (2 * i - 4) * 1024);
+        glds16_s(__umul24((uint32_t)min(prow[2 * i - 3], wcl), ldb32) + (uint32_t)pslot[2 * i - 3], ws, wdst + (2 * i - 3) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -973,13 +988,14 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       if (i == 3)   // `pf_sink` is tied in and out: its register stays reserved for the whole loop (the load lands late)
         asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_off), "s"(pf_base + min(kt + PF, KT - 1) * BK) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // everything but the prefetch just issued
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // all but the 4 weight pieces and the prefetch just issued
     __syncthreads();
   }
   first_issued = ahead;
-  // the stage buffer of the last k-step is free for the epilogue; with `ahead` the other one holds the next tile's
-  // first stage
-  char* const free_buf = smem + ((step - 1) & 1) * STAGE;
+  // the activation stage and the weight stage of the last k-step are free for the epilogue (32 KiB each; the others
+  // hold or are receiving the next tile's first k-steps): waves 0..3 use the one, waves 4..7 the other
+  char* const free_x = smem + TL_XST(step - 1);
+  char* const free_w = smem + TL_WST(step - 1);
 
   // ---- epilogue: lane holds out[m = m0 + wm*128 + 16i + r16][n = n0 + wn*64 + 16j + 4q + r]
   if constexpr (EPI == 1) {
@@ -1007,8 +1023,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     }
     const float qs = *epi.q_scale;
     const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
-    f32x4* mine = (f32x4*)(free_buf + wave * 8192);           // [8 fragments][64 lanes]
-    const f32x4* theirs = (const f32x4*)(free_buf + (wave ^ 2) * 8192);
+    f32x4* mine = (f32x4*)((wave < 4 ? free_x : free_w) + (wave & 3) * 8192);           // [8 fragments][64 lanes]
+    const f32x4* theirs = (const f32x4*)((wave < 4 ? free_x : free_w) + ((wave ^ 2) & 3) * 8192);
     const int ib = up ? 4 : 0;                                // the rows this wave finishes: i = ib .. ib + 3
     uint32_t wq[4][4];
 #pragma unroll
@@ -1047,7 +1063,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       // full tiles leave as whole 128-byte lines (the tile's 128 fp8 columns of a row), staged per 128-row half:
       // [128 rows][128 B], 16-byte chunk c of row R at position c ^ (R & 7).  Straight from the MFMA layout it was
       // 4-byte stores, 16 rows x 16 B per instruction.
-      char* stg = free_buf + wm * 16384;
+      char* stg = wm == 0 ? free_x : free_w;        // 16 KiB per 128-row half
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -1104,7 +1120,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     // first stage: 0.74 of the 1.95 ms of a 16384 x 28672 x 4096 GEMM (probe: tools/src/lds_fill.hip; k-loop alone
     // 1.21 ms, persistent with these stores 1.23 ms).  LDS image: [64 rows][128 B], 16-byte chunk c of row R at
     // position c ^ (R & 7) (the 8-byte writes of the MFMA layout then spread over all banks).
-    char* stg = free_buf + wave * 8192;
+    char* stg = (wave < 4 ? free_x : free_w) + (wave & 3) * 8192;
     const int pr = lane >> 3, pc = lane & 7;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1177,6 +1193,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #undef TL_FRAG
 #undef TL_XOFF
 #undef TL_WOFF
+#undef TL_XST
+#undef TL_WST
 }
 
 
@@ -1220,7 +1238,7 @@ template <typename OutT> static void launch_tile(const GemmParams& p, hipStream_
   if (S > 1 && (!workspace || workspace_bytes < (int64_t)S * p.M * p.N * (int64_t)sizeof(float))) S = 1;
   // S == 1: persistent, one workgroup per CU walks its share of the tiles; split-K: one workgroup per (tile, split)
   const unsigned gx = S == 1 ? (unsigned)tile_grid(mblocks * nblocks) : (unsigned)(mblocks * nblocks);
-  fp8_gemm_tile_kernel<OutT><<<dim3(gx, (unsigned)S), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, (float*)workspace, S);
+  fp8_gemm_tile_kernel<OutT><<<dim3(gx, (unsigned)S), 512, 5 * 256 * 128, st>>>(p, mblocks, nblocks, (float*)workspace, S);
   if (S > 1) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, (const float*)workspace, S);
@@ -1354,9 +1372,9 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
     const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(I / 128);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MI_BF16)
-      fp8_gemm_tile_kernel<bf16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+      fp8_gemm_tile_kernel<bf16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 5 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
     else
-      fp8_gemm_tile_kernel<f16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 2 * 2 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
+      fp8_gemm_tile_kernel<f16_t, 1><<<(unsigned)tile_grid((int)(mblocks * nblocks)), 512, 5 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, epi);
     MI_CHECK_LAUNCH();
     return MI_OK;
   }

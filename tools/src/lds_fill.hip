@@ -431,6 +431,141 @@ __global__ __launch_bounds__(512) void gemm_persist(const uint8_t* __restrict__ 
 #undef FRAG
 }
 
+// mode 8: gemm_persist with a SPLIT ring: activations two stages (one k-step ahead), weights THREE stages requested
+// TWO k-steps ahead (all 160 KiB of LDS) -- the weights are what comes from HBM, the activations are re-read from L2 /
+// Infinity Cache by every n-block.  Per k-step a wave requests its 4 x pieces first, then its 4 w pieces, and waits
+// with vmcnt(4): the x stage of the next step has landed, the weights of the step after may still fly.
+__global__ __launch_bounds__(512) void gemm_split(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, int mblocks,
+                                                  int nblocks, int K, float* out, uint16_t* __restrict__ obuf,
+                                                  const float* __restrict__ sa, const float* __restrict__ sb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4, wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+  const int nwg = mblocks * nblocks, orig = blockIdx.x, G = gridDim.x;
+  const int xcd = orig & 7, slot = orig >> 3, gx = (G - xcd + 7) >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int start = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+  const int cnt = qd + (xcd < rm ? 1 : 0);
+  const int GM = 8, per_group = GM * nblocks;
+  const int KT = K / 128;
+  const size_t N = (size_t)nblocks * 256;
+  auto decode = [&](int li, int& mb, int& nb) {
+    const int tid = start + li;
+    const int grp = tid / per_group, in_grp = tid % per_group;
+    const int first_m = grp * GM, gsz = min(mblocks - first_m, GM);
+    mb = first_m + in_grp % gsz;
+    nb = in_grp / gsz;
+  };
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_base + wave * 4 * 1024);
+  uint32_t off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int line = piece * 4 + (lane >> 4), logical = (lane & 15) ^ (line & 15);
+    const int row = line * 2 + (logical >> 3), sl = logical & 7;
+    off[i] = (uint32_t)(row * K + sl * 16);
+  }
+#define FRAG(base_, row_, slot_) \
+  (*(const uint4*)((base_) + ((row_) >> 1) * 256 + (((((row_) & 1) << 3) | (slot_)) ^ (((row_) >> 1) & 15)) * 16))
+#define XST(s_) ((uint32_t)((s_) & 1) * 32768u)
+#define WST(s_) (65536u + (uint32_t)((s_) % 3) * 32768u)
+  int step = 0;
+  bool first_issued = false;
+  for (int li = slot; li < cnt; li += gx) {
+    int mb, nb, mbn = 0, nbn = 0;
+    decode(li, mb, nb);
+    const bool has_next = li + gx < cnt;
+    if (has_next) decode(li + gx, mbn, nbn); else { mbn = mb; nbn = nb; }
+    const uint8_t* xb0 = uniform_ptr(x + (size_t)mb * 256 * K);
+    const uint8_t* wb0 = uniform_ptr(w + (size_t)nb * 256 * K);
+    const uint8_t* xbn = uniform_ptr(x + (size_t)mbn * 256 * K);
+    const uint8_t* wbn = uniform_ptr(w + (size_t)nbn * 256 * K);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first_issued) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16_s(off[i], xb0, lds_piece + XST(step) + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16_s(off[i], wb0, lds_piece + WST(step) + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16_s(off[i], wb0 + 128, lds_piece + WST(step + 1) + i * 1024);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    for (int kt = 0; kt < KT; ++kt, ++step) {
+      const uint8_t* xs = kt + 1 < KT ? xb0 + (size_t)(kt + 1) * 128 : xbn;                    // x of the next k-step
+      const uint8_t* ws = kt + 2 < KT ? wb0 + (size_t)(kt + 2) * 128 : wbn + (size_t)(kt + 2 - KT) * 128;   // w two ahead
+      const uint32_t xdst = lds_piece + XST(step + 1), wdst = lds_piece + WST(step + 2);
+      const char* xb = smem + XST(step);
+      const char* wb = smem + WST(step);
+      i32x8 wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + r16;
+        const uint4 a0 = FRAG(wb, row, q), a1 = FRAG(wb, row, 4 + q);
+        wf[j] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + r16;
+        const uint4 b0 = FRAG(xb, row, q), b1 = FRAG(xb, row, 4 + q);
+        const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        if (i < 2) {            // the 4 x pieces first ...
+          glds16_s(off[2 * i], xs, xdst + (2 * i) * 1024);
+          glds16_s(off[2 * i + 1], xs, xdst + (2 * i + 1) * 1024);
+        } else if (i < 4) {     // ... then the 4 w pieces: they may stay in flight across the wait
+          glds16_s(off[2 * i - 4], ws, wdst + (2 * i - 4) * 1024);
+          glds16_s(off[2 * i - 3], ws, wdst + (2 * i - 3) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __syncthreads();
+    }
+    first_issued = has_next;
+    {
+      // free after the last k-step: x stage (step - 1) & 1 and w stage (step - 1) % 3, 32 KiB each: waves 0..3 / 4..7
+      char* stg = smem + (wave < 4 ? XST(step - 1) : WST(step - 1)) + (wave & 3) * 8192;
+      const float sav = sa[0], sbv = sb[0];
+      const int pr = lane >> 3, pc = lane & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 2 * j + (q >> 1);
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const int i = h * 4 + ii, row = ii * 16 + r16;
+            uint32_t lo, hi;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(acc[i][j][0] * sav * sbv), "v"(acc[i][j][1] * sav * sbv));
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(acc[i][j][2] * sav * sbv), "v"(acc[i][j][3] * sav * sbv));
+            *(uint2*)(stg + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = make_uint2(lo, hi);
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int row = ps * 8 + pr;
+          const uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
+          const size_t m = (size_t)mb * 256 + wm * 128 + h * 64 + row;
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+          __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, (u32x4_t*)(obuf + m * N + (size_t)nb * 256 + wn * 64 + pc * 8));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef FRAG
+#undef XST
+#undef WST
+}
+
 int main() {
   const size_t region = 8u << 20;
   uint4* src; float* out;
@@ -512,6 +647,16 @@ int main() {
           CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
           CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 12;
           printf("%-44s K=%5d N=%5d %8.3f ms  (%.0f TFLOP/s)\n", "persistent NT, one weight buffer, 12 launches", K, Nn, ms, 2.0 * M * Nn * K / ms / 1e9);
+          {
+            for (int r = 0; r < 4; ++r) gemm_split<<<256, 512, 163840>>>(x, wr[r], mblocks, nblocks, K, out, ob, sc, sc + 1);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int rep = 0; rep < 3; ++rep)
+              for (int r = 0; r < 4; ++r) gemm_split<<<256, 512, 163840>>>(x, wr[r], mblocks, nblocks, K, out, ob, sc, sc + 1);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); t /= 12;
+            printf("%-44s K=%5d N=%5d %8.3f ms  (%.0f TFLOP/s)\n", "split ring (w 2 ahead), rotating weights", K, Nn, t, 2.0 * M * Nn * K / t / 1e9);
+          }
           for (int r = 0; r < 4; ++r) CK(hipFree(wr[r]));
         }
         rung("k-loop + bf16 epilogue (8-byte stores)", [&] { gemm_loop<true, true, false, 1><<<mblocks * nblocks, 512, 131072>>>(x, w, mblocks, nblocks, K, out, ob, sc, sc + 1); });
