@@ -379,7 +379,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2_fast(float a, fl
 }
 
 template <typename T, int HG, int NW>   // NW waves per workgroup: 8 (128-key tiles, one workgroup per CU) or 4 (64-key tiles, two)
-__global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendParams p) {
+__global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendParams p, int nqb, int nreq) {
   constexpr int D = 128, KT = 16 * NW, ROWB = 256;   // four staging passes of NW * 4 key rows
   constexpr int RP = NW * 4;
   constexpr int TB = NW / HG;           // 32-token blocks per workgroup
@@ -391,15 +391,27 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int qb = gridDim.x - 1 - blockIdx.x;   // causal: the blocks with the most keys first
   const int hgroups = p.group / HG;
-  const int hk = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
-  const int req = blockIdx.z;
+  // Items = (q block, head group, request), numbered q-block-MAJOR with the blocks that see the most keys first: the
+  // launch starts with the heaviest block of every (head group, request) and ends with the lightest ones, so the tail
+  // of the launch is filled with short items.  (Until round 2 the q block was the FASTEST grid index: each (head
+  // group, request) ran heavy-to-light on its own, heavy blocks kept arriving until the very end and the last CUs
+  // finished long after the first -- 16 x 2048 causal 1.11 ms against 0.95 ms in this order, 8 x 2048 0.59 / 0.43.)
+  // A workgroup takes items blockIdx.x, + gridDim.x, ...: the launch is normally one workgroup per item.
+  const int gy = p.num_kv_heads * hgroups;
+  const int per_level = gy * nreq;
+  const int total = nqb * per_level;
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  const int qb = nqb - 1 - item / per_level;
+  const int rem = item % per_level;
+  const int by = rem % gy;
+  const int hk = by / hgroups, hg = by % hgroups;
+  const int req = rem / gy;
   const int32_t q_start = p.qo_indptr[req];
   const int32_t ext_len = p.qo_indptr[req + 1] - q_start;
   const int32_t kv_base = p.kv_indptr[req];
   const int32_t prefix = p.kv_indptr[req + 1] - kv_base;
-  if (qb * BQ >= ext_len) return;       // whole workgroup, before any barrier
+  if (qb * BQ >= ext_len) continue;     // whole workgroup, before any barrier of this item
 
   const int head = hk * p.group + hg * HG + (wave % HG);
   const int tok0 = qb * BQ + (wave / HG) * 32;
@@ -651,6 +663,8 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
                                     (st_u32x4*)((T*)p.o + (int64_t)(q_start + tok0 + row) * p.stride_o_tok + (int64_t)head * D + 8 * pc));
     }
   }
+  __syncthreads();     // the staged outputs have been read: the next item may fill the stage buffers
+  }   // items of this workgroup
 }
 
 template <typename T, int D, int HG, bool KV8>
@@ -670,6 +684,20 @@ static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_exte
   }
 }
 
+static int x32_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  // measured 16 x 2048 causal: one workgroup per item in this order 0.95 ms, persistent (one workgroup per CU walking
+  // its items) 0.94 ms; 4 x 8192: 2.74 / 2.81 ms -- the hardware dispatcher keeps ragged batches balanced, so the
+  // one-item-per-workgroup launch is the default and the persistent walk stays selectable
+  static const int persist = mi_tune("MI_EXTEND_PERSIST", 0);
+  return persist ? cus : 0x7fffffff;
+}
+
 // the 32x32x16 form: its preconditions (see extend_attn32_kernel) and its launch
 template <typename T>
 static bool try_launch_extend32(const ExtendParams& p, int64_t batch, int64_t max_extend_len, hipStream_t st) {
@@ -680,8 +708,11 @@ static bool try_launch_extend32(const ExtendParams& p, int64_t batch, int64_t ma
   const int g = p.group;
 #define X32(HGV, NWV)                                                                                                     \
   {                                                                                                                       \
-    dim3 grid((unsigned)cdiv64(max_extend_len, 32 * NWV / HGV), (unsigned)(p.num_kv_heads * (g / HGV)), (unsigned)batch); \
-    extend_attn32_kernel<T, HGV, NWV><<<grid, NWV * 64, 2 * 2 * 16 * NWV * 256, st>>>(p);                                  \
+    const int64_t nqb_ = cdiv64(max_extend_len, 32 * NWV / HGV);                                                          \
+    const int64_t items_ = nqb_ * p.num_kv_heads * (g / HGV) * batch;                                                     \
+    if (items_ > 0x7fffffff) return false;                                                                                \
+    const unsigned grid_ = (unsigned)(items_ < (int64_t)x32_cus() ? items_ : (int64_t)x32_cus());                         \
+    extend_attn32_kernel<T, HGV, NWV><<<grid_, NWV * 64, 2 * 2 * 16 * NWV * 256, st>>>(p, (int)nqb_, (int)batch);         \
   }
   // (a 4-wave / 64-key-tile form, two workgroups per CU, was 1.6x slower: 1.09 vs 0.67 ms on 8 x 2048 causal)
   if (g % 8 == 0) X32(8, 8) else if (g % 4 == 0) X32(4, 8) else if (g % 2 == 0) X32(2, 8) else X32(1, 8)
