@@ -70,7 +70,7 @@ template <typename T> __device__ __forceinline__ uint4 fp8x8_to_T(uint2 u) {
 // (never the softmax denominator).  The new tokens (k_ext / v_ext) stay T-typed and unscaled.
 template <typename T, int D, int HG, int RT, int KH, bool KV8>  // HG q heads per workgroup (1, 2 or 4)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))   // <= 256 registers: two workgroups per CU
-void extend_attn_kernel(const ExtendParams p) {
+void extend_attn_kernel(const ExtendParams p, int nqb, int gy) {
   constexpr int KS = D / 32;
   constexpr int DB = D / 16;
   constexpr int ROW = D * 2 + 32;       // padded LDS row, bytes
@@ -84,12 +84,17 @@ void extend_attn_kernel(const ExtendParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g4 = lane >> 4, c16 = lane & 15;
-  const int qb = gridDim.x - 1 - blockIdx.x;   // causal: the blocks with the most keys are dispatched first (shorter tail)
+  // one-dimensional launch, q-block-major with the blocks that see the most keys first (see extend_attn32_kernel):
+  // block index = ((nqb - 1 - qb) * gz + bz) * gy + by
+  const int per_level = (int)(gridDim.x / (unsigned)nqb);
+  const int qb = nqb - 1 - (int)blockIdx.x / per_level;
+  const int rem = (int)blockIdx.x % per_level;
+  const int by = rem % gy, bz = rem / gy;
   const int hgroups = p.group / HG;
-  const int hk = blockIdx.y / hgroups;
-  const int hg = blockIdx.y % hgroups;
-  const int req = blockIdx.z / p.num_splits;
-  const int split = blockIdx.z % p.num_splits;
+  const int hk = by / hgroups;
+  const int hg = by % hgroups;
+  const int req = bz / p.num_splits;
+  const int split = bz % p.num_splits;
 
   const int32_t q_start = p.qo_indptr[req];
   const int32_t ext_len = p.qo_indptr[req + 1] - q_start;
@@ -673,14 +678,16 @@ static void launch_extend(const ExtendParams& p, int64_t batch, int64_t max_exte
   // measured (8 x 2048 causal, Llama-3-8B heads): <1,2> 0.656 ms (419 TFLOP/s, 112 VGPRs: 4 workgroups per CU),
   // <2,4> 0.873 ms (209 VGPRs: 2 per CU) -- occupancy beats fragment reuse here; the big form stays selectable
   static const int big = mi_tune("MI_EXTEND_BIG", 0);
+  const int gy = (int)(p.num_kv_heads * (p.group / HG));
+  const int64_t gz = batch * p.num_splits;
   if (big && max_extend_len > 16) {       // 128 rows x 64-key tiles, double-buffered
     constexpr int BQ = 128 / HG;
-    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)(batch * p.num_splits));
-    extend_attn_kernel<T, D, HG, 2, 4, KV8><<<grid, 256, 2 * 2 * 64 * ROW, st>>>(p);
+    const int64_t nqb = cdiv64(max_extend_len, BQ);
+    extend_attn_kernel<T, D, HG, 2, 4, KV8><<<(unsigned)(nqb * gy * gz), 256, 2 * 2 * 64 * ROW, st>>>(p, (int)nqb, gy);
   } else {                                // short extends (speculative verify, chunk tails): 64 rows x 32-key tiles
     constexpr int BQ = 64 / HG;
-    dim3 grid((unsigned)cdiv64(max_extend_len, BQ), (unsigned)(p.num_kv_heads * (p.group / HG)), (unsigned)(batch * p.num_splits));
-    extend_attn_kernel<T, D, HG, 1, 2, KV8><<<grid, 256, 2 * 2 * 32 * ROW, st>>>(p);
+    const int64_t nqb = cdiv64(max_extend_len, BQ);
+    extend_attn_kernel<T, D, HG, 1, 2, KV8><<<(unsigned)(nqb * gy * gz), 256, 2 * 2 * 32 * ROW, st>>>(p, (int)nqb, gy);
   }
 }
 
@@ -748,6 +755,8 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
   MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
   MI_CHECK_ARG(num_splits >= 1 && num_splits <= 64 && batch * num_splits <= 65535);
+  // one-dimensional launches: (q blocks of >= 16 rows) x heads x (requests x splits) workgroups
+  MI_CHECK_ARG(cdiv64(max_extend_len, 16) * num_q_heads * batch * num_splits < (1ll << 31));
   MI_CHECK_ARG(num_splits == 1 || (workspace && total_tokens > 0 && ((uintptr_t)workspace & 15) == 0));
   MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
   if (head_dim != 64 && head_dim != 128)
