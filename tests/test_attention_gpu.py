@@ -853,3 +853,29 @@ class SimpleNamespaceLike:
     def __init__(self, runner, page_size):
         self.__dict__.update(runner.__dict__)
         self.page_size = page_size
+
+
+def test_extend_output_row_pitch_fallback():
+    """The 32x32 extend kernel stores 16-byte pieces of whole head rows: an output whose row pitch is not a multiple of
+    8 elements (or is misaligned) must take the 16x16 kernel and give the same answer."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, S, Hq, Hkv, D, dtype = 3, 160, 8, 2, 128, torch.bfloat16
+    E = B * S
+    q = torch.randn(E, Hq, D, generator=g).to(dtype).to(DEV)
+    k = torch.randn(E, Hkv, D, generator=g).to(dtype).to(DEV)
+    v = torch.randn(E, Hkv, D, generator=g).to(dtype).to(DEV)
+    kb = torch.zeros(2, Hkv, D, dtype=dtype, device=DEV)
+    ext = torch.full((B,), S, dtype=torch.int32, device=DEV)
+    pre = torch.zeros(B, dtype=torch.int32, device=DEV)
+    qo, kvp = ops.kv_indptr(ext), ops.kv_indptr(pre).clone()
+    idx = torch.ones(1, dtype=torch.int32, device=DEV)
+    o_ref = torch.empty_like(q)
+    ops.extend_attention(q, k, v, o_ref, kb, kb, qo, kvp, idx, S, D ** -0.5, 0.0, True, -1)
+    big = torch.zeros(E, Hq * D + 4, dtype=dtype, device=DEV)          # row pitch 1028: a multiple of 4, not of 8
+    o_pitch = big[:, : Hq * D].unflatten(1, (Hq, D))
+    assert o_pitch.stride(0) == Hq * D + 4 and o_pitch.stride(1) == D
+    ops.extend_attention(q, k, v, o_pitch, kb, kb, qo, kvp, idx, S, D ** -0.5, 0.0, True, -1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o_pitch.float(), o_ref.float(), atol=4e-3, rtol=2 ** -6)
+    assert float(big[:, Hq * D:].abs().max()) == 0.0                   # nothing written past the rows
