@@ -143,6 +143,47 @@ class MiAttnBackend(AttentionBackend):
                 best, best_cost = s, cost
         return best
 
+    def _ragged_chunk(self, lens: torch.Tensor, mx: int, cap: int) -> int:
+        """Keys per split of a ragged batch.  Floor: `min_split_chunk` (512) and mx / cap (the split capacity of the
+        workspace).  Above the floor the chunk is chosen by simulating the launch: the list's items (full chunks, then
+        the remainders by decreasing length) are handed in order to the first free of the chip's co-resident workgroup
+        slots, an item costs its keys + a fixed ramp; the chunk with the smallest makespan (+ the merge walk) wins --
+        with 512-key chunks the 257 k keys of the B = 128, S_i ~ U[1, 4096] batch are 570 items = 2.2 rounds of 256."""
+        import heapq
+        floor = max(getattr(self, "min_split_chunk", 512), -(-mx // cap))
+        floor = (floor + 15) // 16 * 16
+        if "min_split_chunk" in self.__dict__:
+            return floor                                    # pinned by the caller (tools/attn_bench.py FLOOR=)
+        slots = self.cu_count * max(1, 8 // self._heads_per_wg())
+        ramp, merge = 96, 0.8
+        lens_l = [int(v) for v in lens.tolist()]
+        best, best_cost = floor, None
+        # candidates: the floor and up to 192 keys above it (measured on that batch: 512 -> 208.7 us, 544 -> 204.5,
+        # 640 -> 220, 768 -> 243, 1024 -> 217 us: the model ranks the neighbourhood of the floor correctly and is too kind
+        # to much larger chunks, whose few long items also lose memory-level parallelism)
+        for chunk in range(floor, floor + 193, 16):
+            items = []
+            rems = []
+            for L in lens_l:
+                items.extend([chunk] * (L // chunk))
+                if L % chunk:
+                    rems.append(L % chunk)
+            items.extend(sorted(rems, reverse=True))
+            if len(items) <= slots:
+                cost = (max(items) if items else 0) + ramp
+            else:
+                free = [0.0] * slots
+                heapq.heapify(free)
+                cost = 0.0
+                for it in items:
+                    t = heapq.heappop(free) + it + ramp
+                    cost = max(cost, t)
+                    heapq.heappush(free, t)
+            cost += merge * -(-mx // chunk)
+            if best_cost is None or cost < best_cost - 1e-9:
+                best, best_cost = chunk, cost
+        return best
+
     def _plan_on_host(self, bs: int, seq_lens_sum: int, seq_lens_cpu=None, force_list: bool = False,
                       cap: Optional[int] = None):
         """(num_kv_splits, split_chunk, host work list or None).  Uniform batches: _choose_splits, no chunk, no list
@@ -164,8 +205,7 @@ class MiAttnBackend(AttentionBackend):
                 return splits, 0, None
             work = torch.stack([torch.arange(bs).repeat(splits), torch.arange(splits).repeat_interleave(bs)], dim=1)
             return splits, 0, work.to(torch.int32)
-        chunk = max(getattr(self, "min_split_chunk", 512), -(-mx // cap))
-        chunk = (chunk + 15) // 16 * 16
+        chunk = self._ragged_chunk(lens, mx, cap)
         nsplit = -(-mx // chunk)
         full, rem = lens // chunk, lens % chunk
         # full chunks: split index outermost so that neighbouring workgroups are different requests (XCD spread)

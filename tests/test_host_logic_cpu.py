@@ -90,14 +90,17 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     g = torch.Generator().manual_seed(0)
     lens = torch.randint(1, 4097, (128,), generator=g)
     ns, chunk, work = be._choose_split_plan(128, int(lens.sum()), lens)
-    assert chunk == 512 and ns == -(-int(lens.max()) // 512) and work.dtype == torch.int32 and work.shape[1] == 2
+    # the chunk sits at or just above the 512-key floor (chosen by simulating the launch: test_ragged_split_chunk_choice)
+    rag_chunk = chunk
+    assert 512 <= chunk <= 704 and chunk % 16 == 0 and ns == -(-int(lens.max()) // chunk)
+    assert work.dtype == torch.int32 and work.shape[1] == 2
     # the list holds every non-empty (request, split) exactly once: full chunks first, remainders longest first
-    want = {(b, s) for b in range(128) for s in range(-(-int(lens[b]) // 512))}
+    want = {(b, s) for b in range(128) for s in range(-(-int(lens[b]) // chunk))}
     got = [tuple(r) for r in work.tolist()]
     assert len(got) == len(want) and set(got) == want
-    nfull = int((lens // 512).sum())
-    assert all(s < int(lens[b]) // 512 for b, s in got[:nfull])
-    tail = [int(lens[b]) % 512 for b, s in got[nfull:]]
+    nfull = int((lens // chunk).sum())
+    assert all(s < int(lens[b]) // chunk for b, s in got[:nfull])
+    tail = [int(lens[b]) % chunk for b, s in got[nfull:]]
     assert tail == sorted(tail, reverse=True) and all(t > 0 for t in tail)
     assert be._choose_split_plan(128, 128 * 2048, None) == (2, 0, None)   # no host-side lengths
     # graph replay: the plan always carries a list (the captured launch reads it); uniform = the full grid, split outermost
@@ -110,7 +113,7 @@ def test_backend_split_heuristic_and_contract(monkeypatch):
     be.init_cuda_graph_state(128, 128, kv_indices_buf=torch.zeros(8, dtype=torch.int32))
     be._write_graph_plan(128, int(lens.sum()), lens)
     buf = be.cuda_graph_plan_buf
-    assert buf[:3].tolist() == [work.shape[0], -(-int(lens.max()) // 512), 512]
+    assert buf[:3].tolist() == [work.shape[0], -(-int(lens.max()) // rag_chunk), rag_chunk]
     assert torch.equal(buf[4: 4 + 2 * work.shape[0]].view(-1, 2), work)
     md = be._graph_metadata(128, None)
     assert md.num_kv_splits == be.max_kv_splits and md.work[0].shape == (128 * be.max_kv_splits, 2) and md.work[1].numel() == 4
@@ -248,3 +251,28 @@ def test_install_scheduler_helpers_binds_the_call_forms():
     assert R.install_scheduler_helpers(sb, fbi)
     assert sb.write_req_to_token_pool_triton[(7,)] is R.write_req_to_token_pool     # kernel[grid](...) form
     assert sb.get_last_loc_triton is R.get_last_loc and fbi.compute_position_triton is R.compute_position
+
+
+def test_ragged_split_chunk_choice():
+    """The ragged decode plan picks its chunk by simulating the launch: a multiple of 16 at or just above the floor,
+    never a worse simulated makespan than the floor itself, and pinned when the caller sets min_split_chunk."""
+    import torch
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    be = MiAttnBackend.__new__(MiAttnBackend)
+    be.num_kv_head, be.cu_count, be.max_kv_splits, be.device = 8, 256, 8, "cpu"
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(1, 4097, (128,), generator=g)
+    mx = int(lens.max())
+    floor = max(512, -(-mx // 8))
+    floor = (floor + 15) // 16 * 16
+    chunk = be._ragged_chunk(lens, mx, 8)
+    assert chunk % 16 == 0 and floor <= chunk <= floor + 192
+    assert be._ragged_chunk(lens, mx, 8) == chunk                       # deterministic
+    nsplit, c2, work = be._plan_on_host(128, int(lens.sum()), lens)
+    assert c2 == chunk and nsplit == -(-mx // chunk)
+    covered = torch.zeros(128, dtype=torch.int64)
+    for b, s_ in work.tolist():                                          # every key of every request exactly once
+        covered[b] += min(chunk, int(lens[b]) - s_ * chunk)
+    assert torch.equal(covered, lens.to(torch.int64))
+    be.min_split_chunk = 640
+    assert be._ragged_chunk(lens, mx, 8) == 640

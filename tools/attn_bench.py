@@ -54,7 +54,8 @@ if os.environ.get('WORKLIST', '0') == '1':      # the backend's ragged plan: fix
     from iaas_sglang_amd.attention_backend import MiAttnBackend
     be = MiAttnBackend.__new__(MiAttnBackend)
     be.num_kv_head, be.cu_count, be.max_kv_splits, be.device = Hkv, ops.cu_count(), int(os.environ.get('MAXS', '8')), dev
-    be.min_split_chunk = int(os.environ.get('FLOOR', '512'))
+    if os.environ.get('FLOOR'):                 # pin the chunk (otherwise the backend's simulated choice)
+        be.min_split_chunk = int(os.environ['FLOOR'])
     ns_, CHUNK, WORK = be._choose_split_plan(B, tot, sl.cpu())
     os.environ['SPLITS'] = str(ns_)
     print(f'work list: {0 if WORK is None else WORK.shape[0]} entries, chunk {CHUNK}, splits {ns_}', flush=True)
