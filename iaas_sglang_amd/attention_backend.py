@@ -98,6 +98,7 @@ class MiAttnBackend(AttentionBackend):
         self.page_size = ps if ps >= 16 and ps & (ps - 1) == 0 else 1
         self.page_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device) if self.page_size > 1 else None
         self.num_draft_tokens = getattr(sa, "speculative_num_draft_tokens", None)
+        self.speculative_num_steps = getattr(sa, "speculative_num_steps", None)     # triton_backend.py:102
         self.mask_indptr = torch.zeros(max_bs + 1, dtype=torch.int64, device=self.device)
         self.kv_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
         self.window_kv_indptr = torch.zeros_like(self.kv_indptr) if self.sliding_window_size else None
@@ -273,9 +274,20 @@ class MiAttnBackend(AttentionBackend):
         bs = forward_batch.batch_size
         mode = forward_batch.forward_mode
         spec_info = getattr(forward_batch, "spec_info", None)
-        if mode.is_draft_extend() or (spec_info is not None and not mode.is_target_verify()):
-            raise NotImplementedError("MiAttnBackend: draft-side speculative modes (DRAFT_EXTEND, draft decode) are out "
-                                      "of scope; TARGET_VERIFY is supported")
+        if mode.is_draft_extend():
+            self.forward_metadata = self._draft_extend_metadata(
+                bs, forward_batch.req_pool_indices, forward_batch.seq_lens, int(forward_batch.seq_lens_sum), spec_info,
+                getattr(forward_batch, "extend_seq_lens_cpu", None), getattr(forward_batch, "seq_lens_cpu", None))
+            return
+        if mode.is_decode_or_idle() and spec_info is not None:
+            # draft decode (triton_backend.py:200-202): the draft worker hands the index arrays over ready-made, one row
+            # per (request, top-k branch); the host does not know the lengths, so the split count is chosen from the total
+            kv_indptr, kv_indices = spec_info.kv_indptr, spec_info.kv_indices
+            rows = kv_indptr.shape[0] - 1
+            splits = self._choose_splits(rows, max(int(kv_indices.shape[0]), rows))
+            self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, None, None, splits,
+                                                    self._workspace(rows, splits))
+            return
         if mode.is_target_verify():
             # triton_backend.py:226-263: every request verifies num_draft_tokens tree nodes against its whole
             # committed sequence ("prefix" = seq_lens) under spec_info.custom_mask
@@ -332,6 +344,75 @@ class MiAttnBackend(AttentionBackend):
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, splits,
                                                     self._workspace(tokens, splits))
 
+    def _draft_extend_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, spec_info, ext_cpu=None,
+                               seq_lens_cpu=None, kv_indices=None, splits=None, workspace=None,
+                               accept_length=None) -> ForwardMetadata:
+        """DRAFT_EXTEND (triton_backend.py:265-283, EagleDraftInput.generate_attn_arg_prefill eagle_utils.py:134-163):
+        after a verify step every request extends its draft-model cache by its `accept_length` newly accepted tokens;
+        `seq_lens` already counts them (eagle_utils.py:593) and `qo_indptr` is the scan of `spec_info.accept_length`.
+        The new rows are attended from the k/v arguments (causal) and everything before them from the pool, so the
+        pool-side index list covers the first seq_len - accept_length keys of each request: every key once, the
+        arithmetic of the torch-native oracle (torch_native_backend.py:27-110).  (The Triton backend lists the whole
+        sequence on the pool side as well, its kernel then meets the new keys twice -- the FIXME at
+        triton_backend.py:276-278; not reproduced.)"""
+        if accept_length is None:
+            if spec_info is None or getattr(spec_info, "accept_length", None) is None:
+                raise ValueError("DRAFT_EXTEND needs spec_info.accept_length")
+            accept_length = spec_info.accept_length
+        acc = accept_length[:bs]
+        acc = acc if acc.dtype in (torch.int32, torch.int64) else acc.to(torch.int32)
+        prefix = (seq_lens[:bs] - acc.to(seq_lens.dtype)).contiguous()
+        cap_ext = int(self.speculative_num_steps or 0) + 1
+        if ext_cpu is not None:
+            ext_l = [int(e) for e in ext_cpu][:bs]
+            max_ext, tokens = max(ext_l), sum(ext_l)
+        else:
+            if cap_ext <= 1:
+                raise ValueError("DRAFT_EXTEND needs forward_batch.extend_seq_lens_cpu or server_args.speculative_num_steps")
+            ext_l, max_ext, tokens = None, cap_ext, bs * cap_ext
+        kv_indptr = ops.kv_indptr(prefix, self.kv_indptr)
+        if kv_indices is None:
+            n = seq_lens_sum - tokens if ext_l is not None else seq_lens_sum
+            kv_indices = torch.empty(max(int(n), 1), dtype=torch.int32, device=self.device)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], prefix, kv_indptr, kv_indices)
+        qo_indptr = ops.kv_indptr(acc.contiguous(), self.qo_indptr)
+        if splits is None:
+            if ext_l is not None and seq_lens_cpu is not None:
+                pre_l = [int(s_) - e for s_, e in zip(torch.as_tensor(seq_lens_cpu)[:bs].tolist(), ext_l)]
+                splits = self._choose_extend_splits(ext_l, pre_l)
+            else:
+                splits = 1
+        if workspace is None and splits > 1:
+            workspace = self._workspace(tokens, splits)
+        return ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, splits, workspace if splits > 1 else None)
+
+    def _graph_extend_splits(self, bs: int, tokens_per_req: int) -> int:
+        """Split-KV count of a CAPTURED verify / draft-extend launch: the grid is frozen, the key ranges are not (each
+        split takes its share of whatever the request holds at replay, empty splits cost a merge step), so the count is
+        chosen from the workgroup count alone, within the workspace init_cuda_graph_state allocated."""
+        group = max(self.num_head // max(self.num_kv_head, 1), 1)
+        hg = 4 if group % 4 == 0 else 2 if group % 2 == 0 else 1
+        wgs = bs * -(-tokens_per_req // (64 // hg)) * self.num_kv_head * (group // hg)
+        return max(1, min(self.max_kv_splits, 1024 // max(wgs, 1)))
+
+    def _verify_graph_metadata(self, bs, req_pool_indices, seq_lens, spec_info, splits=None) -> ForwardMetadata:
+        """TARGET_VERIFY into the persistent buffers (capture triton_backend.py:445-475, replay :579-607)."""
+        nd = int(self.num_draft_tokens or 0)
+        if nd <= 0 or spec_info is None or getattr(spec_info, "custom_mask", None) is None:
+            raise ValueError("TARGET_VERIFY needs server_args.speculative_num_draft_tokens and spec_info.custom_mask")
+        qo_indptr = self.qo_indptr[: bs + 1]
+        qo_indptr.copy_(torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int32, device=self.device))
+        kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
+        ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
+        cm = spec_info.custom_mask
+        self.cuda_graph_custom_mask[: cm.shape[0]].copy_(cm.view(torch.uint8) if cm.dtype == torch.bool else cm)
+        mask_indptr = self.mask_indptr[: bs + 1]
+        mask_indptr[1: bs + 1] = torch.cumsum(nd * (seq_lens[:bs].to(torch.int64) + nd), dim=0)
+        splits = self._graph_extend_splits(bs, nd) if splits is None else splits
+        return ForwardMetadata(kv_indptr, self.cuda_graph_kv_indices, qo_indptr, nd, splits,
+                               self.cuda_graph_workspace if splits > 1 else None,
+                               custom_mask=self.cuda_graph_custom_mask.view(torch.bool), mask_indptr=mask_indptr)
+
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
         """Preallocate everything replay touches (triton_backend.py:338-388).  Beyond the reference's buffers: the
         decode PLAN.  A captured launch bakes its grid and scalar arguments in, so the captured decode kernels take
@@ -344,6 +425,9 @@ class MiAttnBackend(AttentionBackend):
         self.cuda_graph_workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
         self._gplan = _GraphPlan(max_num_tokens * self.max_kv_splits, self.device)
         self.cuda_graph_plan_buf = self._gplan.buf
+        if not self.skip_prefill:                                   # triton_backend.py:366-371
+            self.cuda_graph_custom_mask = torch.zeros(max_num_tokens * self.max_context_len, dtype=torch.uint8,
+                                                      device=self.device)
         if self.page_size > 1:
             self.cuda_graph_page_indices = torch.zeros(max_num_tokens * (-(-self.max_context_len // self.page_size)),
                                                        dtype=torch.int32, device=self.device)
@@ -400,8 +484,26 @@ class MiAttnBackend(AttentionBackend):
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
                                                  forward_mode, spec_info):
         assert encoder_lens is None, "Not supported"
-        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+        if forward_mode.is_target_verify():
+            self.forward_metadata = self._verify_graph_metadata(bs, req_pool_indices, seq_lens, spec_info)
+            return
+        if forward_mode.is_draft_extend():
+            # triton_backend.py:476-503: speculative_num_steps + 1 query rows per request at capture time; replay
+            # rewrites qo_indptr from spec_info.accept_length (shorter requests leave their last blocks idle)
+            per = int(self.speculative_num_steps or 0) + 1
+            acc = getattr(spec_info, "accept_length", None)
+            if acc is None:
+                acc = torch.full((bs,), per, dtype=torch.int32, device=self.device)
+            self.forward_metadata = self._draft_extend_metadata(
+                bs, req_pool_indices, seq_lens, 0, spec_info, None, None, kv_indices=self.cuda_graph_kv_indices,
+                splits=self._graph_extend_splits(bs, per), workspace=self.cuda_graph_workspace, accept_length=acc)
+            return
+        if not forward_mode.is_decode_or_idle():
             raise ValueError(f"Invalid forward mode: {forward_mode=} for graph capture.")
+        if spec_info is not None:                # draft decode: the draft worker's own persistent index arrays (:433-434)
+            self.forward_metadata = ForwardMetadata(spec_info.kv_indptr, spec_info.kv_indices, None, None,
+                                                    self.max_kv_splits, self.cuda_graph_workspace)
+            return
         kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)
         # the captured launch covers the whole capacity bs x max_kv_splits of the work list; which entries are live,
@@ -419,8 +521,19 @@ class MiAttnBackend(AttentionBackend):
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
-        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+        if forward_mode.is_target_verify():
+            self._verify_graph_metadata(len(req_pool_indices), req_pool_indices, seq_lens, spec_info)
+            return
+        if forward_mode.is_draft_extend():       # triton_backend.py:608-624: qo_indptr and the index list, no sync
+            self._draft_extend_metadata(bs, req_pool_indices, seq_lens, 0, spec_info, None, None,
+                                        kv_indices=self.cuda_graph_kv_indices, splits=1)
+            return
+        if not forward_mode.is_decode_or_idle():
             raise ValueError(f"Invalid forward mode: {forward_mode=} for graph replay.")
+        if spec_info is not None:                # draft decode (triton_backend.py:575-578)
+            self.kv_indptr[: spec_info.kv_indptr.shape[0]].copy_(spec_info.kv_indptr)
+            self.cuda_graph_kv_indices[: spec_info.kv_indices.shape[0]].copy_(spec_info.kv_indices)
+            return
         # no allocation, no host sync: two kernels into persistent buffers (triton_backend.py:544-566) and the plan
         kv_indptr = ops.kv_indptr(seq_lens[:bs], self.kv_indptr)
         ops.kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr, self.cuda_graph_kv_indices)

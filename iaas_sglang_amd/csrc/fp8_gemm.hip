@@ -22,6 +22,7 @@ struct GemmParams {
   void* out;
   int64_t M, N, K, lda, ldb, ldo;
   int sa_row, sb_row, rotate;
+  int var;      // fp8_gemm_xd_kernel schedule bits (xd_var())
 };
 
 template <typename OutT, int MT>
@@ -537,6 +538,25 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
 
 
 
+// schedule bits of fp8_gemm_xd_kernel: 1 = non-temporal weight DMA, 2 = waves 4-7 compute before they issue (stagger),
+// 4 = all fragment reads of a phase ahead of its MFMAs, 8 = s_setprio 1 on waves 4-7
+#ifdef MI_TUNING
+// diagnostic build only: per (workgroup, wave) cycle sums of the phase segments of fp8_gemm_xd_kernel (var bit 16)
+__device__ unsigned long long mi_xd_stamps[512 * 8 * 8];
+extern "C" int mi_debug_xd_stamps(unsigned long long* host_out, int clear) {
+  if (clear) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(mi_xd_stamps)) != hipSuccess) return -1;
+    return hipMemset(d, 0, sizeof(unsigned long long) * 512 * 8 * 8) == hipSuccess ? 0 : -1;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi_xd_stamps), sizeof(unsigned long long) * 512 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+static int xd_var() {
+  static const int v = mi_tune("MI_XD_VAR", 0);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp8_gemm_xd_kernel: the decode-shaped GEMM with a DEEP ring of 128-byte k-phases.
 //
@@ -600,6 +620,9 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     xlds[i] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
   }
   const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_base + XBYTES + wave * 2 * 1024);
+  const int var = p.var;
+  const bool late = (var & 2) && __builtin_amdgcn_readfirstlane(wave) >= 4;   // stagger: waves 4-7 compute, then issue
+  if ((var & 8) && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
 
   auto issue = [&](int64_t ph) __attribute__((always_inline)) {
     const uint32_t st = (uint32_t)((ph - ph0) % R) * STAGE;
@@ -607,8 +630,13 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     const uint8_t* wa = p.b + ph * PB;
 #pragma unroll
     for (int i = 0; i < XD; ++i) glds16_s(xoff[i], xa, xlds[i] + st);
-    glds16_s(woff[0], wa, wlds + st);
-    glds16_s(woff[1], wa, wlds + st + 1024);
+    if (var & 1) {
+      glds16_s_nt(woff[0], wa, wlds + st);
+      glds16_s_nt(woff[1], wa, wlds + st + 1024);
+    } else {
+      glds16_s(woff[0], wa, wlds + st);
+      glds16_s(woff[1], wa, wlds + st + 1024);
+    }
   };
   // fragment (row, 16-byte slot) of a tile whose rows are 128 B: line pair = row >> 1, physical position
   // ((row & 1) * 8 + slot) ^ (line & 15)
@@ -630,22 +658,93 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (ph0 + d < ph1) issue(ph0 + d);
+#ifdef MI_TUNING
+    unsigned long long t_cmp = 0, t_wait = 0, t_bar = 0, t_prev = 0, t_iss = 0, t_rd = 0, t_mma = 0;
+    const bool stamp = (var & 16) != 0;
+#endif
     for (int64_t ph = ph0; ph < ph1; ++ph) {
+#ifdef MI_TUNING
+      if (stamp) {   // wait_phase split into its two halves
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+        const int64_t after = min((int64_t)(D - 1), ph1 - 1 - ph);
+        if (D >= 4 && after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * E) : "memory");
+        else if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+        if (t_prev) t_cmp += ta - t_prev;
+        t_wait += tb - ta;
+        t_bar += tc - tb;
+        t_prev = tc;
+        if (var & 32) {   // finer: DMA issue | fragment reads | MFMAs, each closed by its own stamp
+          if (ph + D < ph1) issue(ph + D);
+          const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+          const char* xb = smem + ((ph - ph0) % R) * STAGE;
+          const char* wb = xb + XBYTES;
+          const uint4 w0 = frag(wb, wave * 16 + r16, q), w1 = frag(wb, wave * 16 + r16, 4 + q);
+          const i32x8 wf = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+          uint4 x0[MT], x1[MT];
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            x0[t] = frag(xb, t * 16 + r16, q);
+            x1[t] = frag(xb, t * 16 + r16, 4 + q);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const i32x8 xf = {(int)x0[t].x, (int)x0[t].y, (int)x0[t].z, (int)x0[t].w,
+                              (int)x1[t].x, (int)x1[t].y, (int)x1[t].z, (int)x1[t].w};
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          }
+          const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+          t_iss += t1 - tc; t_rd += t2 - t1; t_mma += t3 - t2;
+          continue;
+        }
+      } else
+#endif
       wait_phase(ph);                                    // phase ph landed everywhere; everyone is done with ph-1
-      if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
+      if (!late && ph + D < ph1) issue(ph + D);          // into the stage phase ph-1 used
       if (tile_ok) {
         const char* xb = smem + ((ph - ph0) % R) * STAGE;
         const char* wb = xb + XBYTES;
         const uint4 w0 = frag(wb, wave * 16 + r16, q), w1 = frag(wb, wave * 16 + r16, 4 + q);
         const i32x8 wf = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+        if (var & 4) {
+          uint4 x0[MT], x1[MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const uint4 x0 = frag(xb, t * 16 + r16, q), x1 = frag(xb, t * 16 + r16, 4 + q);
-          const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          for (int t = 0; t < MT; ++t) {
+            x0[t] = frag(xb, t * 16 + r16, q);
+            x1[t] = frag(xb, t * 16 + r16, 4 + q);
+          }
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const i32x8 xf = {(int)x0[t].x, (int)x0[t].y, (int)x0[t].z, (int)x0[t].w,
+                              (int)x1[t].x, (int)x1[t].y, (int)x1[t].z, (int)x1[t].w};
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * MT, 0);   // every fragment read of the phase first
+          __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);           // then the MFMAs back to back
+        } else {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const uint4 x0 = frag(xb, t * 16 + r16, q), x1 = frag(xb, t * 16 + r16, 4 + q);
+            const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+          }
         }
       }
+      if (late && ph + D < ph1) issue(ph + D);
     }
+#ifdef MI_TUNING
+    if (stamp && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+      unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      o[0] += t_cmp; o[1] += t_wait; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
+      o[4] += t_iss; o[5] += t_rd; o[6] += t_mma;
+    }
+#endif
     __syncthreads();                                     // the epilogue may reuse LDS
   }
   xs_epilogue<OutT, MT, NWV, EPI>(p, slab, S, sp, force_slab, epi, acc, smem, n0, c0, Ihalf, tile_ok, lane, wave);
@@ -1317,6 +1416,7 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
   {
     static const int rot_env = gemm_rotate();
     p.rotate = rot_env;
+    p.var = xd_var();
   }
   hipStream_t st = (hipStream_t)stream;
   MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
@@ -1343,7 +1443,7 @@ MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slab
   MI_CHECK_ARG((((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)slabs) & 15) == 0);
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = nullptr; p.sb = nullptr; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
   int S, ppw;
   xs_plan(N, K, &S, &ppw);
   hipStream_t st = (hipStream_t)stream;
@@ -1367,7 +1467,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
     // prefill: the 256 x 256 tile kernel with the same epilogue (a tile = 128 gate + 128 up rows of the weights)
     GemmParams p;
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
     const SiluEpi epi{(uint8_t*)q_out, q_scale};
     const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(I / 128);
     hipStream_t st = (hipStream_t)stream;
@@ -1386,7 +1486,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   if (S != 1) return 1;
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate();
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
