@@ -23,6 +23,7 @@ struct GemmParams {
   int64_t M, N, K, lda, ldb, ldo;
   int sa_row, sb_row, rotate;
   int var;      // fp8_gemm_xd_kernel schedule bits (xd_var())
+  int rot_step; // fp8_gemm_xw_kernel: phase rotation step across workgroups
 };
 
 template <typename OutT, int MT>
@@ -542,16 +543,20 @@ __global__ __launch_bounds__(NWV * 64) void fp8_gemm_xs_kernel(const GemmParams 
 // 4 = all fragment reads of a phase ahead of its MFMAs, 8 = s_setprio 1 on waves 4-7
 #ifdef MI_TUNING
 // diagnostic build only: per (workgroup, wave) cycle sums of the phase segments of fp8_gemm_xd_kernel (var bit 16)
-__device__ unsigned long long mi_xd_stamps[512 * 8 * 8];
+__device__ unsigned long long mi_xd_stamps[512 * 12 * 8];
 extern "C" int mi_debug_xd_stamps(unsigned long long* host_out, int clear) {
   if (clear) {
     void* d = nullptr;
     if (hipGetSymbolAddress(&d, HIP_SYMBOL(mi_xd_stamps)) != hipSuccess) return -1;
-    return hipMemset(d, 0, sizeof(unsigned long long) * 512 * 8 * 8) == hipSuccess ? 0 : -1;
+    return hipMemset(d, 0, sizeof(unsigned long long) * 512 * 12 * 8) == hipSuccess ? 0 : -1;
   }
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi_xd_stamps), sizeof(unsigned long long) * 512 * 8 * 8) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi_xd_stamps), sizeof(unsigned long long) * 512 * 12 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
+static int xw_rot() {
+  static const int v = mi_tune("MI_XW_ROT", 7);
+  return v;
+}
 static int xd_var() {
   static const int v = mi_tune("MI_XD_VAR", 0);
   return v;
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     }
 #ifdef MI_TUNING
     if (stamp && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
-      unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
       o[0] += t_cmp; o[1] += t_wait; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
       o[4] += t_iss; o[5] += t_rd; o[6] += t_mma;
     }
@@ -748,6 +753,406 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     __syncthreads();                                     // the epilogue may reuse LDS
   }
   xs_epilogue<OutT, MT, NWV, EPI>(p, slab, S, sp, force_slab, epi, acc, smem, n0, c0, Ihalf, tile_ok, lane, wave);
+}
+// ---------------------------------------------------------------------------------------------
+// fp8_gemm_xw_kernel: the decode-shaped GEMM with wave ROLES (round 3).
+//
+// In-kernel stamps of fp8_gemm_xd_kernel (tools/xd_stamps.py, gate_up shape 128 x 28672 x 4096, cycles per 128-byte
+// phase and wave): 376 blocked in the issue of its 4 DMA pieces (all 8 waves queue 32 pieces on the CU's one address
+// path at once), 630 for its 18 fragment reads (every wave reads the WHOLE x stage: 8 x 18 KiB = 144 KiB per phase
+// through a 256 B/clk LDS = 576 cycles), ~260 of MFMA, 280 in the barrier (the older half waits for the younger) and
+// only ~100 waiting for data: the phase is a sum of three lock-stepped segments, not memory.  Re-ordering inside the
+// wave (stagger, fragment prefetch, priorities, non-temporal weights) changed nothing measurable.  So:
+//   * waves 4-7 are LOADERS: they only issue LDS-DMA (4 weight + XL activation pieces each per phase), wait for
+//     their pieces with a counted vmcnt and meet the barrier; blocked issue slots cost nobody anything;
+//   * waves 0-3 are CONSUMERS, one per SIMD, each owning 32 weight rows x all M rows: an x fragment now feeds two
+//     MFMAs, the LDS read volume per phase drops from 144 KiB to 4 x 20 KiB, and nothing but ds_read + MFMA is in
+//     their instruction stream.
+// Same LDS image, ring, phase order and MFMA operands as fp8_gemm_xd_kernel: results are bit-identical to it.
+// Weight-block row j of the workgroup (0..127) is output column nb*128 + j, or with EPI = 1 (gate_up + SiLU*mul):
+// j < 64 -> gate column 64*nb + j, else the up column I + 64*nb + j - 64; consumers 0,1 end with gate values and
+// consumers 2,3 with the up values of the same columns in the same registers.
+template <typename OutT, int MT, int EPI, int R>
+__global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, float* __restrict__ slab, int S,
+                                                          int phases_per_wg /* 128-byte phases */, int force_slab,
+                                                          const SiluEpi epi, int staged /* epilogue through LDS */) {
+  constexpr int PB = 128, D = R - 1, NL = 4;
+  constexpr int ROWS = MT * 16;
+  constexpr int XBYTES = ROWS * PB, WBYTES = 128 * PB, STAGE = XBYTES + WBYTES;
+  constexpr int XP = ROWS / 8;                          // x DMA pieces (8 rows x 128 B) per phase
+  constexpr int XL = XP >= NL ? XP / NL : 1;            // per loader (small M: loaders re-fetch a piece)
+  constexpr int WL = 16 / NL;                           // weight pieces per loader
+  constexpr int E = XL + WL;                            // vmcnt entries per loader per phase
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t Ihalf = p.N / 2;
+  const int sp = blockIdx.y;
+  const int64_t NPH = p.K / PB;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(NPH, ph0 + phases_per_wg);
+  const uint32_t lds_base = lds_addr_of(smem);
+#ifdef MI_TUNING
+  const unsigned long long t_k0 = (p.var & 16) ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long r_k0 = (p.var & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
+  // output column of weight-block row j
+  auto col_of = [&](int j) __attribute__((always_inline)) -> int64_t {
+    if (EPI) return (j < 64 ? 0 : Ihalf - 64) + (int64_t)blockIdx.x * 64 + j;
+    return (int64_t)blockIdx.x * 128 + j;
+  };
+
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- loaders
+    const int ld = wave - 4;
+    const int dline = lane >> 4, dpos = lane & 15;
+    uint32_t woff[WL], xoff[XL], wlds[WL], xlds[XL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int piece = ld * WL + i;
+      const int line = piece * 4 + dline;
+      const int logical = dpos ^ (line & 15);
+      const int j = line * 2 + (logical >> 3);
+      woff[i] = (uint32_t)(min(col_of(j), p.N - 1) * p.ldb + (logical & 7) * 16);
+      wlds[i] = __builtin_amdgcn_readfirstlane(lds_base + XBYTES + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int piece = (ld * XL + i) % XP;
+      const int line = piece * 4 + dline;
+      const int logical = dpos ^ (line & 15);
+      const int row = line * 2 + (logical >> 3);
+      xoff[i] = (uint32_t)(min((int64_t)row, p.M - 1) * p.lda + (logical & 7) * 16);
+      xlds[i] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
+    }
+    // Workgroup b walks its phases cyclically from phase (7 b) % count: at any moment the workgroups of the chip then
+    // ask for different k-slices of x and of their weight rows, instead of the same 128-byte column of every row
+    // (same L2 / memory channels for everybody).  Measured on the gate_up shape once the kernel was DMA-bound:
+    // 35.4 -> 30.8 us, any odd step 3..23 and an XCD-wise offset alike; split-K shapes (4-14 phases) are unchanged.
+    // Only the loaders know: the consumers accumulate stages in arrival order (a fixed order per workgroup).
+    const int64_t nphw = ph1 - ph0;
+    const int64_t rot = nphw > 0 ? ((int64_t)blockIdx.x * p.rot_step) % nphw : 0;
+    auto issue = [&](int64_t ph) __attribute__((always_inline)) {
+      const uint32_t st = (uint32_t)((ph - ph0) % R) * STAGE;
+      int64_t kph = ph + rot;
+      kph = kph >= ph1 ? kph - nphw : kph;
+      const uint8_t* xa = p.a + kph * PB;                // wave-uniform: scalar arithmetic
+      const uint8_t* wa = p.b + kph * PB;
+#pragma unroll
+      for (int i = 0; i < XL; ++i) glds16_s(xoff[i], xa, xlds[i] + st);
+#pragma unroll
+      for (int i = 0; i < WL; ++i) glds16_s(woff[i], wa, wlds[i] + st);
+    };
+    static_assert(D >= 2 && D <= 4, "the wait enumerates up to 3 phases in flight");
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (ph0 + d < ph1) issue(ph0 + d);
+#ifdef MI_TUNING
+    unsigned long long t_iss = 0, t_wait = 0, t_bar = 0;
+    const bool stamp = (p.var & 16) != 0;
+#endif
+    for (int64_t ph = ph0; ph < ph1; ++ph) {
+#ifdef MI_TUNING
+      const unsigned long long ta = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      const int64_t after = min((int64_t)(D - 1), ph1 - 1 - ph);   // phases issued after ph may stay in flight
+      if (D >= 4 && after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * E) : "memory");
+      else if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MI_TUNING
+      const unsigned long long tb = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      __builtin_amdgcn_s_barrier();                      // phase ph published; the consumers are done with ph-1
+#ifdef MI_TUNING
+      const unsigned long long tc = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
+#ifdef MI_TUNING
+      if (stamp) {
+        const unsigned long long td = __builtin_amdgcn_s_memtime();
+        t_wait += tb - ta; t_bar += tc - tb; t_iss += td - tc;
+      }
+#endif
+    }
+#ifdef MI_TUNING
+    if (stamp && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+      unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+      o[0] += t_iss; o[1] += t_wait; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
+    }
+#endif
+    __builtin_amdgcn_s_barrier();                        // (the consumers' "LDS may be reused" barrier)
+    if (!staged) {
+      if constexpr (EPI == 1) __builtin_amdgcn_s_barrier();   // (the exchange barrier of the per-lane epilogue)
+      return;
+    }
+  }
+
+  // ------------------------------------------------------------------ consumers
+  f32x4 acc[2][MT];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[tn][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment (row, 16-byte slot) of a tile whose rows are 128 B: line pair = row >> 1, physical position
+  // ((row & 1) * 8 + slot) ^ (line & 15)
+  auto frag = [&](const char* base, int row, int slot) __attribute__((always_inline)) -> uint4 {
+    return *(const uint4*)(base + (row >> 1) * 256 + (((((row & 1) << 3) | slot) ^ ((row >> 1) & 15)) * 16));
+  };
+  if (wave < 4) {
+#ifdef MI_TUNING
+  unsigned long long t_cmp = 0, t_bar = 0, t_prev = 0;
+  const bool stamp = (p.var & 16) != 0;
+#endif
+  for (int64_t ph = ph0; ph < ph1; ++ph) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MI_TUNING
+    const unsigned long long ta = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+    __builtin_amdgcn_s_barrier();                        // phase ph landed (the loaders waited for it)
+#ifdef MI_TUNING
+    if (stamp) {
+      const unsigned long long tb = __builtin_amdgcn_s_memtime();
+      if (t_prev) t_cmp += ta - t_prev;
+      t_bar += tb - ta;
+      t_prev = tb;
+    }
+#endif
+    const char* xb = smem + ((ph - ph0) % R) * STAGE;
+    const char* wb = xb + XBYTES;
+    i32x8 wf[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int j = wave * 32 + tn * 16 + r16;
+      const uint4 w0 = frag(wb, j, q), w1 = frag(wb, j, 4 + q);
+      wf[tn] = i32x8{(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+    }
+    uint4 x0[MT], x1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      x0[t] = frag(xb, t * 16 + r16, q);
+      x1[t] = frag(xb, t * 16 + r16, 4 + q);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const i32x8 xf = {(int)x0[t].x, (int)x0[t].y, (int)x0[t].z, (int)x0[t].w,
+                        (int)x1[t].x, (int)x1[t].y, (int)x1[t].z, (int)x1[t].w};
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        acc[tn][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xf, acc[tn][t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    // one wave per SIMD: nothing else hides the LDS latency, so the x fragments run PF m tiles ahead of their MFMAs
+    constexpr int PF = MT < 2 ? MT : 2;
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * PF, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      if (t + PF < MT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+  }
+#ifdef MI_TUNING
+  if (stamp && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+    unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+    o[0] += t_cmp; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
+    o[4] += __builtin_amdgcn_s_memtime() - t_k0;          // kernel entry -> end of the main loop
+    o[5] += __builtin_amdgcn_s_memrealtime() - r_k0;      // the same in 100 MHz ticks
+    o[6] = r_k0;                                          // absolute (chip-wide 100 MHz counter), last launch
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every stage consumed: the epilogue may reuse LDS
+  }
+
+#ifdef MI_TUNING
+  if (p.var & 64) return;                                // diagnostic: no epilogue at all (bounds what the stores cost)
+#endif
+  // ------------------------------------------------------------------ epilogue through LDS (`staged`): the consumers
+  // park their [MT*16 rows m][128 block columns j] fp32 tile in the free stages (rows padded to 528 B: conflict-free
+  // ds_write_b128), then ALL 8 waves write it out in whole rows.  Measured before this form existed (per-lane stores
+  // straight from the MFMA layout: 16 rows x 64 B -- or 16 B with EPI -- per instruction, and with EPI the SiLU
+  // arithmetic of a 128 x 64 tile on two waves): 4.3-8.1 us of a 13-37 us kernel went to the epilogue.
+  if (staged) {
+    constexpr int TP = 128 * 4 + 16;
+    const bool to_slab = !EPI && (S > 1 || force_slab);
+    if (wave < 4) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        float sbv[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!to_slab) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t n = min(col_of(wave * 32 + tn * 16 + 4 * q + r), p.N - 1);
+            sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+            bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = acc[tn][t];
+          if (!to_slab) {
+            const int64_t m = min((int64_t)t * 16 + r16, p.M - 1);
+            const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float y = v[r] * sav * sbv[r] + bv[r];
+              v[r] = EPI ? round_to<OutT>(y) : y;
+            }
+          }
+          *(f32x4*)(smem + (t * 16 + r16) * TP + (wave * 32 + tn * 16 + 4 * q) * 4) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == 1) {
+      // lane -> row 16*wave + lane/4, output columns 16*(lane%4) .. +15 of the workgroup's 64: one 16-byte store
+      const int row = wave * 16 + (lane >> 2), c = lane & 3;
+      if (row < ROWS && row < p.M) {
+        const float qs = *epi.q_scale;
+        const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+        const char* gp = smem + row * TP + c * 64;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 g4 = *(const f32x4*)(gp + k * 16), u4 = *(const f32x4*)(gp + 256 + k * 16);
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = g4[r];
+            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u4[r]);
+            o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+          }
+          w[k] = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+          w[k] = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w[k], true);
+        }
+        *(uint4*)(epi.q_out + (int64_t)row * Ihalf + (int64_t)blockIdx.x * 64 + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    } else if (to_slab) {
+      float* sbp = slab + (int64_t)sp * p.M * p.N + (int64_t)blockIdx.x * 128;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {                     // 16 rows per pass: wave -> 2 rows x 512 B
+        const int row = i * 16 + wave * 2 + (lane >> 5), c = lane & 31;
+        if (row < p.M) *(f32x4*)(sbp + (int64_t)row * p.N + c * 4) = *(const f32x4*)(smem + row * TP + c * 16);
+      }
+    } else {
+      OutT* op = (OutT*)p.out + (int64_t)blockIdx.x * 128;
+#pragma unroll
+      for (int i = 0; i < (MT + 1) / 2; ++i) {           // 32 rows per pass: wave -> 4 rows x 256 B
+        const int row = i * 32 + wave * 4 + (lane >> 4), c = lane & 15;
+        if (row < ROWS && row < p.M) {
+          const f32x4 a = *(const f32x4*)(smem + row * TP + c * 32), b = *(const f32x4*)(smem + row * TP + c * 32 + 16);
+          *(uint4*)(op + (int64_t)row * p.ldo + c * 8) =
+              make_uint4(pack2<OutT>(a[0], a[1]), pack2<OutT>(a[2], a[3]), pack2<OutT>(b[0], b[1]), pack2<OutT>(b[2], b[3]));
+        }
+      }
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ epilogue (consumer `wave`, tile tn: columns
+  // col_of(32*wave + 16*tn + 4*q + r), rows 16*t + r16)
+  if constexpr (EPI == 1) {
+    f32x4* xch = (f32x4*)smem;                           // [2 up consumers][2][MT][64] f32x4
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      float sbv[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = min(col_of(wave * 32 + tn * 16 + 4 * q + r), p.N - 1);
+        sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+        bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int64_t m = min((int64_t)t * 16 + r16, p.M - 1);
+        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tn][t][r] = round_to<OutT>(acc[tn][t][r] * sav * sbv[r] + bv[r]);
+        if (wave >= 2) xch[(((wave - 2) * 2 + tn) * MT + t) * 64 + lane] = acc[tn][t];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 2) return;
+    const float qs = *epi.q_scale;
+    const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int64_t c = (int64_t)blockIdx.x * 64 + wave * 32 + tn * 16 + 4 * q;     // output column (of Ihalf)
+      if (c >= Ihalf) continue;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int64_t m = (int64_t)t * 16 + r16;
+        if (m >= p.M) continue;
+        const f32x4 u = xch[((wave * 2 + tn) * MT + t) * 64 + lane];
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[tn][t][r];
+          o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+          o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
+        }
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+        *(uint32_t*)(epi.q_out + m * Ihalf + c) = w;
+      }
+    }
+    return;
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int64_t nb = col_of(wave * 32 + tn * 16 + 4 * q);
+      if (nb >= p.N) continue;
+      if (S > 1 || force_slab) {                         // fp32 partial tile -> slab[sp][m][n]
+        float* sbp = slab + (int64_t)sp * p.M * p.N;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int64_t m = (int64_t)t * 16 + r16;
+          if (m >= p.M) continue;
+          float* o = sbp + m * p.N + nb;
+          if (nb + 3 < p.N && (p.N & 3) == 0) {
+            *(f32x4*)o = acc[tn][t];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (nb + r < p.N) o[r] = acc[tn][t][r];
+          }
+        }
+        continue;
+      }
+      float sbv[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = min(nb + r, p.N - 1);
+        sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
+        bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int64_t m = (int64_t)t * 16 + r16;
+        if (m >= p.M) continue;
+        const float sav = p.sa_row ? p.sa[m] : p.sa[0];
+        OutT* o = (OutT*)p.out + m * p.ldo + nb;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[tn][t][r] * sav * sbv[r] + bv[r];
+        if (nb + 3 < p.N && (p.ldo & 3) == 0) {
+          *(uint2*)o = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < p.N) o[r] = (OutT)v[r];
+        }
+      }
+    }
+  }
+}
+// LDS of the role kernel: its ring, and never less than the staged output tile (MT*16 rows of 528 B)
+static size_t xw_lds(int mt, int r) {
+  const size_t ring = (size_t)r * ((size_t)mt * 16 * 128 + 128 * 128), tile = (size_t)mt * 16 * 528;
+  return ring > tile ? ring : tile;
 }
 // LDS of the deep-ring kernel: 4 stages of (x [M x 128 B] + 8 x 2 KiB of weights); never below the EPI exchange buffer
 static size_t xd_lds(int mt, int r) { return (size_t)r * ((size_t)mt * 16 * 128 + 8 * 16 * 128); }
@@ -823,11 +1228,20 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   const int fs = partial ? 1 : 0;
   static const int split = mi_tune("MI_GEMM_XS_SPLIT", 1);
   static const int deep = mi_tune("MI_GEMM_XD", 1);
+  static const int roles = mi_tune("MI_GEMM_XW", 1);    // 0: fp8_gemm_xd_kernel; bit 1 set: per-lane epilogue
   if constexpr (MT == 16) {
     // 129..256 rows in one pass over the weights: 48-KiB stages (x 32 KiB + weights 16 KiB), ring of 3
     fp8_gemm_xd_kernel<OutT, 16, 0, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   } else
-  if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
+  if (nw == 8 && roles) {
+    // whole-row epilogue: every block column exists and the rows of the destination take 16-byte stores
+    const bool to_slab = S > 1 || partial;
+    const int staged = (roles & 2) == 0 && p.N % 128 == 0 &&
+                       (to_slab ? ((uintptr_t)slab & 15) == 0 : (p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0));
+    if (roles & 4) fp8_gemm_xw_kernel<OutT, MT, 0, 5><<<grid, 512, xw_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
+    else fp8_gemm_xw_kernel<OutT, MT, 0, 4><<<grid, 512, xw_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
+  }
+  else if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && deep) fp8_gemm_xd_kernel<OutT, MT, 0, 4><<<grid, 512, xd_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
   else if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
@@ -1416,7 +1830,7 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
   {
     static const int rot_env = gemm_rotate();
     p.rotate = rot_env;
-    p.var = xd_var();
+    p.var = xd_var(); p.rot_step = xw_rot();
   }
   hipStream_t st = (hipStream_t)stream;
   MI_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 0);
@@ -1443,7 +1857,7 @@ MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slab
   MI_CHECK_ARG((((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)slabs) & 15) == 0);
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = nullptr; p.sb = nullptr; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var(); p.rot_step = xw_rot();
   int S, ppw;
   xs_plan(N, K, &S, &ppw);
   hipStream_t st = (hipStream_t)stream;
@@ -1467,7 +1881,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
     // prefill: the 256 x 256 tile kernel with the same epilogue (a tile = 128 gate + 128 up rows of the weights)
     GemmParams p;
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var(); p.rot_step = xw_rot();
     const SiluEpi epi{(uint8_t*)q_out, q_scale};
     const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(I / 128);
     hipStream_t st = (hipStream_t)stream;
@@ -1486,13 +1900,17 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   if (S != 1) return 1;
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var();
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var(); p.rot_step = xw_rot();
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
   static const int deep = mi_tune("MI_GEMM_XD", 1);
+  static const int roles = mi_tune("MI_GEMM_XW", 1);    // 0: fp8_gemm_xd_kernel; bit 1 set: per-lane epilogue
+  const int staged = (roles & 2) == 0 && I % 16 == 0 && ((uintptr_t)q_out & 15) == 0;
 #define LAUNCH_EPI(TT, MTV)                                                                                    \
-  if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
+  if (roles & 4) fp8_gemm_xw_kernel<TT, MTV, 1, 5><<<grid, 512, xw_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
+  else if (roles) fp8_gemm_xw_kernel<TT, MTV, 1, 4><<<grid, 512, xw_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
+  else if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
   if (dtype == MI_BF16) {
