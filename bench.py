@@ -197,6 +197,13 @@ def ragged_attention_leg(H, stack, runner, backend, B, S, dev, reps=2):
     fb = H.make_decode_batch(runner, backend, B, 0, dev, seed=1, ragged=lens)
     backend.init_forward_metadata(fb)
     md = backend.forward_metadata
+    # host time of the plan itself (what init_forward_metadata / graph replay spend on it before the launches)
+    import time
+    backend._plan_on_host(B, int(lens.sum()), fb.seq_lens_cpu)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        backend._plan_on_host(B, int(lens.sum()), fb.seq_lens_cpu)
+    plan_ms = (time.perf_counter() - t0) / 5 * 1e3
     s = stack.shape
     q = torch.randn(B, stack.Hq, s.head_dim, device=dev, dtype=torch.float32).to(stack.dtype)
     o = torch.empty_like(q)
@@ -223,7 +230,7 @@ def ragged_attention_leg(H, stack, runner, backend, B, S, dev, reps=2):
     nbytes = 2 * tot * stack.Hkv * s.head_dim * 2 + 2 * B * stack.Hq * s.head_dim * 2 + 4 * tot
     return {"keys": tot, "max_len": int(lens.max()), "min_len": int(lens.min()), "avg_launch_us": round(t * 1e6, 2),
             "achieved_GBps": round(nbytes / t / 1e9, 1), "kv_splits": md.num_kv_splits, "split_chunk": md.split_chunk,
-            "work_items": None if md.work is None else int(md.work.shape[0])}
+            "work_items": None if md.work is None else int(md.work.shape[0]), "plan_host_ms": round(plan_ms, 3)}
 
 
 MFMA_PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)

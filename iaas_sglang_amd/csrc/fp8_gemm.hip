@@ -772,16 +772,18 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
 // Weight-block row j of the workgroup (0..127) is output column nb*128 + j, or with EPI = 1 (gate_up + SiLU*mul):
 // j < 64 -> gate column 64*nb + j, else the up column I + 64*nb + j - 64; consumers 0,1 end with gate values and
 // consumers 2,3 with the up values of the same columns in the same registers.
-template <typename OutT, int MT, int EPI, int R>
+template <typename OutT, int MT, int EPI, int R, int NT = 2>   // NT = 16-row weight tiles per consumer: block of 64 NT rows
 __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, float* __restrict__ slab, int S,
                                                           int phases_per_wg /* 128-byte phases */, int force_slab,
                                                           const SiluEpi epi, int staged /* epilogue through LDS */) {
   constexpr int PB = 128, D = R - 1, NL = 4;
   constexpr int ROWS = MT * 16;
-  constexpr int XBYTES = ROWS * PB, WBYTES = 128 * PB, STAGE = XBYTES + WBYTES;
+  constexpr int WR = 64 * NT;                           // weight rows (= output columns) of the workgroup
+  constexpr int XBYTES = ROWS * PB, WBYTES = WR * PB, STAGE = XBYTES + WBYTES;
+  static_assert(NT == 2 || (NT == 1 && EPI == 0), "the SiLU form pairs 64 gate with 64 up rows");
   constexpr int XP = ROWS / 8;                          // x DMA pieces (8 rows x 128 B) per phase
   constexpr int XL = XP >= NL ? XP / NL : 1;            // per loader (small M: loaders re-fetch a piece)
-  constexpr int WL = 16 / NL;                           // weight pieces per loader
+  constexpr int WL = WR / 8 / NL;                       // weight pieces per loader
   constexpr int E = XL + WL;                            // vmcnt entries per loader per phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
   // output column of weight-block row j
   auto col_of = [&](int j) __attribute__((always_inline)) -> int64_t {
     if (EPI) return (j < 64 ? 0 : Ihalf - 64) + (int64_t)blockIdx.x * 64 + j;
-    return (int64_t)blockIdx.x * 128 + j;
+    return (int64_t)blockIdx.x * WR + j;
   };
 
   if (wave >= 4) {
@@ -890,9 +892,9 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
   }
 
   // ------------------------------------------------------------------ consumers
-  f32x4 acc[2][MT];
+  f32x4 acc[NT][MT];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
+  for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[tn][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // fragment (row, 16-byte slot) of a tile whose rows are 128 B: line pair = row >> 1, physical position
@@ -921,10 +923,10 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
 #endif
     const char* xb = smem + ((ph - ph0) % R) * STAGE;
     const char* wb = xb + XBYTES;
-    i32x8 wf[2];
+    i32x8 wf[NT];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int j = wave * 32 + tn * 16 + r16;
+    for (int tn = 0; tn < NT; ++tn) {
+      const int j = wave * (16 * NT) + tn * 16 + r16;
       const uint4 w0 = frag(wb, j, q), w1 = frag(wb, j, 4 + q);
       wf[tn] = i32x8{(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
     }
@@ -939,16 +941,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
       const i32x8 xf = {(int)x0[t].x, (int)x0[t].y, (int)x0[t].z, (int)x0[t].w,
                         (int)x1[t].x, (int)x1[t].y, (int)x1[t].z, (int)x1[t].w};
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < NT; ++tn)
         acc[tn][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xf, acc[tn][t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     }
     // one wave per SIMD: nothing else hides the LDS latency, so the x fragments run PF m tiles ahead of their MFMAs
     constexpr int PF = MT < 2 ? MT : 2;
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * PF, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2 * PF, 0);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       if (t + PF < MT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
     }
   }
 #ifdef MI_TUNING
@@ -974,16 +976,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
   // straight from the MFMA layout: 16 rows x 64 B -- or 16 B with EPI -- per instruction, and with EPI the SiLU
   // arithmetic of a 128 x 64 tile on two waves): 4.3-8.1 us of a 13-37 us kernel went to the epilogue.
   if (staged) {
-    constexpr int TP = 128 * 4 + 16;
+    constexpr int TP = WR * 4 + 16;
     const bool to_slab = !EPI && (S > 1 || force_slab);
     if (wave < 4) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
+      for (int tn = 0; tn < NT; ++tn) {
         float sbv[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (!to_slab) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int64_t n = min(col_of(wave * 32 + tn * 16 + 4 * q + r), p.N - 1);
+            const int64_t n = min(col_of(wave * (16 * NT) + tn * 16 + 4 * q + r), p.N - 1);
             sbv[r] = p.sb_row ? p.sb[n] : p.sb[0];
             bv[r] = p.bias ? (float)((const OutT*)p.bias)[n] : 0.f;
           }
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
               v[r] = EPI ? round_to<OutT>(y) : y;
             }
           }
-          *(f32x4*)(smem + (t * 16 + r16) * TP + (wave * 32 + tn * 16 + 4 * q) * 4) = v;
+          *(f32x4*)(smem + (t * 16 + r16) * TP + (wave * (16 * NT) + tn * 16 + 4 * q) * 4) = v;
         }
       }
     }
@@ -1030,17 +1032,19 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
         *(uint4*)(epi.q_out + (int64_t)row * Ihalf + (int64_t)blockIdx.x * 64 + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     } else if (to_slab) {
-      float* sbp = slab + (int64_t)sp * p.M * p.N + (int64_t)blockIdx.x * 128;
+      float* sbp = slab + (int64_t)sp * p.M * p.N + (int64_t)blockIdx.x * WR;
+      constexpr int LPR = WR / 4, RPW = 64 / LPR;        // lanes per row (16 B each), rows per wave instruction
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {                     // 16 rows per pass: wave -> 2 rows x 512 B
-        const int row = i * 16 + wave * 2 + (lane >> 5), c = lane & 31;
-        if (row < p.M) *(f32x4*)(sbp + (int64_t)row * p.N + c * 4) = *(const f32x4*)(smem + row * TP + c * 16);
+      for (int i = 0; i < (ROWS + 8 * RPW - 1) / (8 * RPW); ++i) {   // 8 RPW rows per pass: wave -> RPW whole rows of 4 WR bytes
+        const int row = (i * 8 + wave) * RPW + lane / LPR, c = lane % LPR;
+        if (row < ROWS && row < p.M) *(f32x4*)(sbp + (int64_t)row * p.N + c * 4) = *(const f32x4*)(smem + row * TP + c * 16);
       }
     } else {
-      OutT* op = (OutT*)p.out + (int64_t)blockIdx.x * 128;
+      OutT* op = (OutT*)p.out + (int64_t)blockIdx.x * WR;
+      constexpr int LPR = WR / 8, RPW = 64 / LPR;        // 8 columns per lane
 #pragma unroll
-      for (int i = 0; i < (MT + 1) / 2; ++i) {           // 32 rows per pass: wave -> 4 rows x 256 B
-        const int row = i * 32 + wave * 4 + (lane >> 4), c = lane & 15;
+      for (int i = 0; i < (ROWS + 8 * RPW - 1) / (8 * RPW); ++i) {   // wave -> RPW whole rows of 2 WR bytes
+        const int row = (i * 8 + wave) * RPW + lane / LPR, c = lane % LPR;
         if (row < ROWS && row < p.M) {
           const f32x4 a = *(const f32x4*)(smem + row * TP + c * 32), b = *(const f32x4*)(smem + row * TP + c * 32 + 16);
           *(uint4*)(op + (int64_t)row * p.ldo + c * 8) =
@@ -1102,8 +1106,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
     return;
   } else {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int64_t nb = col_of(wave * 32 + tn * 16 + 4 * q);
+    for (int tn = 0; tn < NT; ++tn) {
+      const int64_t nb = col_of(wave * (16 * NT) + tn * 16 + 4 * q);
       if (nb >= p.N) continue;
       if (S > 1 || force_slab) {                         // fp32 partial tile -> slab[sp][m][n]
         float* sbp = slab + (int64_t)sp * p.M * p.N;
@@ -1150,8 +1154,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
   }
 }
 // LDS of the role kernel: its ring, and never less than the staged output tile (MT*16 rows of 528 B)
-static size_t xw_lds(int mt, int r) {
-  const size_t ring = (size_t)r * ((size_t)mt * 16 * 128 + 128 * 128), tile = (size_t)mt * 16 * 528;
+static size_t xw_lds(int mt, int r, int width = 128) {
+  const size_t ring = (size_t)r * ((size_t)mt * 16 * 128 + (size_t)width * 128), tile = (size_t)mt * 16 * ((size_t)width * 4 + 16);
   return ring > tile ? ring : tile;
 }
 // LDS of the deep-ring kernel: 4 stages of (x [M x 128 B] + 8 x 2 KiB of weights); never below the EPI exchange buffer
@@ -1205,26 +1209,48 @@ static int xs_waves(int64_t N) {
   return (big == 8 && N >= 1024) ? 8 : 4;
 }
 
-static void xs_plan(int64_t N, int64_t K, int* S, int* ppw) {
-  const int64_t nblk = cdiv64(N, 16 * xs_waves(N)), nph = cdiv64(K / 128, 2);
+// Split-K plan of the decode kernels: S slices of `ppw` 256-byte phases, and (role kernel only) the width of a
+// workgroup's column block.  128 columns minimise what a CU ingests per output ((M + width) x k bytes at ~45 GB/s,
+// tools/xd_stamps.py) but need the deepest split to fill the chip, and every slab byte is written (~4 TB/s as measured:
+// 16.8 MB of o_proj slabs = 4.4 us of a 14.9-us kernel) and read again by the consumer kernel; 64 columns halve the
+// split.  The cheaper of the two by that model: 64 for the 4096 x 4096 o_proj (S 8 -> 4), 128 for qkv / down / gate_up.
+static void xs_plan(int64_t M, int64_t N, int64_t K, int* S, int* ppw, int* width = nullptr) {
   static const int target = mi_tune("MI_GEMM_XS_TARGET", 256);   // one round of workgroups on 256 CUs
-  int64_t want = nblk >= 200 ? 1 : target / nblk;
-  if (want < 1) want = 1;
-  if (want > nph) want = nph;
-  const int64_t per = cdiv64(nph, want);
-  *ppw = (int)per;
-  *S = (int)cdiv64(nph, per);
+  static const int roles = mi_tune("MI_GEMM_XW", 1), narrow = mi_tune("MI_GEMM_XW_NARROW", 1);
+  const int64_t nph = cdiv64(K / 128, 2);
+  auto plan = [&](int64_t w, int* s_out, int* per_out) -> double {
+    const int64_t nblk = cdiv64(N, w);
+    int64_t want = nblk >= 200 ? 1 : target / nblk;
+    if (want < 1) want = 1;
+    if (want > nph) want = nph;
+    const int64_t per = cdiv64(nph, want), s = cdiv64(nph, per);
+    *s_out = (int)s;
+    *per_out = (int)per;
+    const double ingest_us = (double)(128 + w) * (double)(per * 256) / 45e3;
+    const double slab_us = s > 1 ? 2.0 * (double)s * 128.0 * (double)N * 4.0 / 4.5e6 : 0.0;
+    const double rounds = (double)cdiv64(nblk * s, 256);
+    return rounds * ingest_us + slab_us;
+  };
+  int s128, per128;
+  const double c128 = plan(16 * xs_waves(N), &s128, &per128);
+  *S = s128; *ppw = per128;
+  if (width) *width = 128;
+  if (width && roles && narrow && xs_waves(N) == 8 && M <= 128 && N % 64 == 0) {
+    int s64, per64;
+    const double c64 = plan(64, &s64, &per64);
+    if (c64 < 0.9 * c128) { *S = s64; *ppw = per64; *width = 64; }
+  }
 }
 
 // LDS of the split ring (8 waves): 2 x stages + 3 weight stages = 160 KiB at M = 128 (all of a gfx950 CU's LDS)
 static size_t xs_split_lds(int mt) { return 2 * (size_t)mt * 16 * 256 + 3 * (size_t)8 * 16 * 256; }
 
 template <typename OutT, int MT>
-static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false) {
+static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false, int width = 128) {
   const int nw = xs_waves(p.N);
   static const int nst4 = mi_tune("MI_GEMM_XS_STAGES", 3);
   const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
-  dim3 grid((unsigned)cdiv64(p.N, 16 * nw), (unsigned)S);
+  dim3 grid((unsigned)cdiv64(p.N, width == 64 ? 64 : 16 * nw), (unsigned)S);
   const int fs = partial ? 1 : 0;
   static const int split = mi_tune("MI_GEMM_XS_SPLIT", 1);
   static const int deep = mi_tune("MI_GEMM_XD", 1);
@@ -1236,9 +1262,9 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
   if (nw == 8 && roles) {
     // whole-row epilogue: every block column exists and the rows of the destination take 16-byte stores
     const bool to_slab = S > 1 || partial;
-    const int staged = (roles & 2) == 0 && p.N % 128 == 0 &&
+    const int staged = (roles & 2) == 0 && p.N % width == 0 &&
                        (to_slab ? ((uintptr_t)slab & 15) == 0 : (p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0));
-    if (roles & 4) fp8_gemm_xw_kernel<OutT, MT, 0, 5><<<grid, 512, xw_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
+    if (width == 64) fp8_gemm_xw_kernel<OutT, MT, 0, 4, 1><<<grid, 512, xw_lds(MT, 4, 64), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
     else fp8_gemm_xw_kernel<OutT, MT, 0, 4><<<grid, 512, xw_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
   }
   else if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
@@ -1286,8 +1312,8 @@ extern "C" int64_t mi_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
     return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
   }
   if (M > mi_fp8_gemm_partial_max_rows(N)) M = mi_fp8_gemm_partial_max_rows(N);   // chunks reuse the same slabs
-  int S, spw;
-  xs_plan(N, K, &S, &spw);
+  int S, spw, width;
+  xs_plan(M, N, K, &S, &spw, &width);
   return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -1763,18 +1789,19 @@ static void launch_fp8_gemm(const GemmParams& p, hipStream_t st, void* workspace
   const int64_t pass_rows = p.M > 128 && p.M <= 256 && p.K % 128 == 0 ? mi_fp8_gemm_partial_max_rows(p.N) : 128;
   if (p.M <= pass_rows && p.K % 128 == 0 && (p.M <= 128 || mid_m_chunked(p.M, p.N, p.K))) {
     // decode shapes: x-stationary, weights streamed once
-    int S, spw;
-    xs_plan(p.N, p.K, &S, &spw);
+    int S, spw, width;
+    xs_plan(p.M, p.N, p.K, &S, &spw, &width);
     const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
     if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {  // no room for slabs: no split-K
       S = 1;
       spw = (int)cdiv64(p.K / 128, 2);
+      width = 128;
     }
     float* slab = (float*)workspace;
-    if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st);
-    else if (p.M <= 32) launch_xs<OutT, 2>(p, slab, S, spw, st);
-    else if (p.M <= 64) launch_xs<OutT, 4>(p, slab, S, spw, st);
-    else if (p.M <= 128) launch_xs<OutT, 8>(p, slab, S, spw, st);
+    if (p.M <= 16) launch_xs<OutT, 1>(p, slab, S, spw, st, false, width);
+    else if (p.M <= 32) launch_xs<OutT, 2>(p, slab, S, spw, st, false, width);
+    else if (p.M <= 64) launch_xs<OutT, 4>(p, slab, S, spw, st, false, width);
+    else if (p.M <= 128) launch_xs<OutT, 8>(p, slab, S, spw, st, false, width);
     else launch_xs<OutT, 16>(p, slab, S, spw, st);
     return;
   }
@@ -1844,8 +1871,8 @@ extern "C" int mi_fp8_gemm(const void* a, const void* b_nk, const float* scale_a
 // sums the slabs and applies scales / residual / norm / rope itself.
 MI_INTERNAL int mi_fp8_gemm_plan_splits(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || M > mi_fp8_gemm_partial_max_rows(N) || K % 128 != 0) return 0;   // 0: the partial form does not apply
-  int S, ppw;
-  xs_plan(N, K, &S, &ppw);
+  int S, ppw, width;
+  xs_plan(M, N, K, &S, &ppw, &width);
   return S;
 }
 
@@ -1858,13 +1885,13 @@ MI_INTERNAL int mi_fp8_gemm_partial(const void* a, const void* b_nk, float* slab
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = nullptr; p.sb = nullptr; p.bias = nullptr; p.out = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = N; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var(); p.rot_step = xw_rot();
-  int S, ppw;
-  xs_plan(N, K, &S, &ppw);
+  int S, ppw, width;
+  xs_plan(M, N, K, &S, &ppw, &width);
   hipStream_t st = (hipStream_t)stream;
-  if (M <= 16) launch_xs<bf16_t, 1>(p, slabs, S, ppw, st, true);
-  else if (M <= 32) launch_xs<bf16_t, 2>(p, slabs, S, ppw, st, true);
-  else if (M <= 64) launch_xs<bf16_t, 4>(p, slabs, S, ppw, st, true);
-  else if (M <= 128) launch_xs<bf16_t, 8>(p, slabs, S, ppw, st, true);
+  if (M <= 16) launch_xs<bf16_t, 1>(p, slabs, S, ppw, st, true, width);
+  else if (M <= 32) launch_xs<bf16_t, 2>(p, slabs, S, ppw, st, true, width);
+  else if (M <= 64) launch_xs<bf16_t, 4>(p, slabs, S, ppw, st, true, width);
+  else if (M <= 128) launch_xs<bf16_t, 8>(p, slabs, S, ppw, st, true, width);
   else launch_xs<bf16_t, 16>(p, slabs, S, ppw, st, true);
   MI_CHECK_LAUNCH();
   return MI_OK;
@@ -1896,7 +1923,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   if ((((uintptr_t)a | (uintptr_t)b_nk) & 15) || ((uintptr_t)q_out & 3)) return 1;
   if (xs_waves(N) != 8 || M > mi_fp8_gemm_partial_max_rows(N)) return 1;
   int S, ppw;
-  xs_plan(N, K, &S, &ppw);
+  xs_plan(M, N, K, &S, &ppw);
   if (S != 1) return 1;
   GemmParams p;
   p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = nullptr;
@@ -1908,8 +1935,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   static const int roles = mi_tune("MI_GEMM_XW", 1);    // 0: fp8_gemm_xd_kernel; bit 1 set: per-lane epilogue
   const int staged = (roles & 2) == 0 && I % 16 == 0 && ((uintptr_t)q_out & 15) == 0;
 #define LAUNCH_EPI(TT, MTV)                                                                                    \
-  if (roles & 4) fp8_gemm_xw_kernel<TT, MTV, 1, 5><<<grid, 512, xw_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
-  else if (roles) fp8_gemm_xw_kernel<TT, MTV, 1, 4><<<grid, 512, xw_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
+  if (roles) fp8_gemm_xw_kernel<TT, MTV, 1, 4><<<grid, 512, xw_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
   else if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)

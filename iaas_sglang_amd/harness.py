@@ -318,16 +318,30 @@ class LlamaStack:
         runs while half B's attention and GEMMs keep the rest of the chip busy, and vice versa.
         Every kernel of the step computes rows independently, so the logits are bit-identical to the serial step.
         The lm_head (a library GEMM, outside the hot path) and the vocabulary all-gather run ONCE on the joined stream
-        over the whole batch: two library GEMMs side by side on two streams hung the GPU (their persistent kernels
-        share scratch), and one M = B GEMM reads the lm_head weights once instead of twice."""
+        over the whole batch (one M = B GEMM reads the lm_head weights once instead of twice).
+        INVARIANT of the per-stream region: only this repository's kernels, each with scratch of its own stream.
+        Round 2 saw the capture of this step hang twice (gpurun_out/tbo_a.err: the watchdog found the host in
+        torch.cuda.synchronize() under the capture barrier) while each half still ran its own lm_head GEMM and while
+        ops._gemm_workspace handed BOTH streams the same split-K slab buffer; both were changed in the same commit, so
+        which of the two removed the hang was never established.  Neither can come back silently:
+        the fused decode path is asserted below (no library GEMM can run in it) and the slab scratch is keyed by
+        stream (asserted below as well)."""
         nA = fbs[0].batch_size
         cur = torch.cuda.current_stream()
         outs = []
         saved = self.custom_ar
+        assert streams[0] != streams[1] and cur not in streams, "two-batch overlap needs two side streams"
+        for i, (lo, hi) in enumerate(((0, nA), (nA, hidden.shape[0]))):
+            if not self._fused_decode_ok(hidden[lo:hi], fbs[i]):
+                raise RuntimeError("forward_decode_two_batch: the per-stream region must be the fused FP8 decode path "
+                                   "(a library GEMM on two streams side by side is not allowed here)")
         try:
             for i, (lo, hi) in enumerate(((0, nA), (nA, hidden.shape[0]))):
                 streams[i].wait_stream(cur)
                 with torch.cuda.stream(streams[i]):
+                    ws_probe = ops._gemm_workspace(16, hidden.device)
+                    assert i == 0 or ws_probe.data_ptr() != ws_first, "split-K scratch must be private to a stream"
+                    ws_first = ws_probe.data_ptr()
                     if custom_ars is not None:
                         self.custom_ar = custom_ars[i]
                     backends[i].init_forward_metadata(fbs[i])

@@ -109,7 +109,16 @@ def load_kv_cache_scales(attn_layers: List[torch.nn.Module], quantization_param_
         attn = attn_layers[layer_idx]
         if not hasattr(attn, "k_scale"):
             raise RuntimeError("Self attention has no KV cache scaling factor attribute!")
-        attn.k_scale = scaling_factor
-        attn.v_scale = scaling_factor
+        # llama.py:371-376 assigns the python float over the attribute; on a layer that went through
+        # Fp8KVCacheMethod.create_weights the attribute is a registered nn.Parameter (a plain assignment raises), and
+        # process_weights_after_loading has already frozen k_scale_float / v_scale_float (1.0 for a checkpoint without
+        # kv scales) -- the file's factor has to replace those too, or the backend would keep reading 1.0
+        for name in ("k_scale", "v_scale"):
+            cur = getattr(attn, name)
+            if isinstance(cur, torch.nn.Parameter) or isinstance(cur, torch.Tensor):
+                cur.data.fill_(scaling_factor)
+            else:
+                setattr(attn, name, scaling_factor)
+            setattr(attn, name + "_float", float(scaling_factor))
         n += 1
     return n

@@ -182,7 +182,7 @@ def test_gptq_fused_gemm_vs_oracle(act_order):
     torch.testing.assert_close(y.cpu().float(), ref, rtol=2 ** -9, atol=3e-2)
     Wd = o_.w4_dequantize(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), g, MI_W4_GPTQ, g_idx.to(DEV))
     assert torch.equal(Wd.cpu(), W.to(torch.float16))
-    # prefill route (dequantise the native layout + dense GEMM; act-order: permuted rows against x[:, perm])
+    # prefill route (w4a16_tile_kernel on the native layout; act-order: mi_gather_columns of x first)
     xl = torch.randn(600, K, generator=gen).to(torch.float16)
     yl = o_.w4a16_gemm(xl.to(DEV), qw, zs, N, g, perm)
     torch.testing.assert_close(yl.cpu().float(), xl.float() @ W.float(), rtol=2 ** -9, atol=3e-2)
