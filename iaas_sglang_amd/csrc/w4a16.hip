@@ -140,6 +140,38 @@ template <> struct Deq<bf16_t> {
   }
 };
 
+// The same dequantisation in four parts (one packed pair of the fragment each), so that a kernel can place them between
+// its MFMAs: DeqQ<T>::Prep holds what a (tile, phase) or a packed dword shares, part<I>() returns dword I of the
+// fragment Deq<T>::run would give -- the same instructions on the same values, bit for bit.
+template <typename T> struct DeqQ;
+template <> struct DeqQ<f16_t> {
+  struct Zs { half2_t sv, zv; };
+  static __device__ __forceinline__ Zs zs(uint32_t v) {
+    return Zs{__builtin_bit_cast(half2_t, (v & 0xffffu) * 0x00010001u), __builtin_bit_cast(half2_t, (v >> 16) * 0x00010001u)};
+  }
+  template <int I> static __device__ __forceinline__ uint32_t part(uint32_t w, const Zs& z) {
+    // (w >> 4 I) & 0x000F000F | 0x64006400 in ONE v_bfi_b32 (hipcc emits v_and + v_or for the C form)
+    uint32_t pair;
+    const uint32_t sh = I ? (w >> (4 * I)) : w;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(pair) : "s"(0x000F000Fu), "v"(sh), "v"(0x64006400u));   // one SGPR per VOP3 (constant bus)
+    half2_t h = __builtin_bit_cast(half2_t, pair);
+    h = (h - z.zv) * z.sv;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+};
+template <> struct DeqQ<bf16_t> {
+  struct Zs { float s, nzs; };
+  static __device__ __forceinline__ Zs zs(uint32_t v) {
+    const float s = __uint_as_float(v << 16);
+    return Zs{s, -((__uint_as_float(v & 0xffff0000u) - 128.f) * s)};
+  }
+  template <int I> static __device__ __forceinline__ uint32_t part(uint32_t w, const Zs& z) {
+    const uint32_t h = ((I & 1) ? (w >> 4) : w) & 0x0f0f0f0fu;       // I = 0, 2: elements (0,4,1,5); 1, 3: (2,6,3,7)
+    if constexpr (I < 2) return pack2<bf16_t>(fmaf(ub<0>(h), z.s, z.nzs), fmaf(ub<2>(h), z.s, z.nzs));
+    else return pack2<bf16_t>(fmaf(ub<1>(h), z.s, z.nzs), fmaf(ub<3>(h), z.s, z.nzs));
+  }
+};
+
 // ------------------------------------------------------------------------------ GEMM
 struct W4Params {
   const void* x;
@@ -331,6 +363,284 @@ __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, fl
       for (int r = 0; r < 4; ++r) bv[r] = p.bias ? (float)((const T*)p.bias)[nb + r] : 0.f;
       *(uint2*)((T*)p.out + m * p.ldo + nb) = make_uint2(pack2<T>(acc[t][0] + bv[0], acc[t][1] + bv[1]),
                                                         pack2<T>(acc[t][2] + bv[2], acc[t][3] + bv[3]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// w4a16_xw_kernel: the decode-shaped int4 GEMM with wave ROLES (round 3; the structure of fp8_gemm_xw_kernel).
+// What the stamps of the FP8 kernel showed applies here more strongly: in w4a16_xs_kernel every one of 8 waves issues
+// DMA, reads the WHOLE activation stage (8 x 16 KiB at M = 64 for 8 KiB of packed weights), dequantises and runs its
+// MFMAs in lock-step (measured: 0.14 of the HBM rate at the C4 shapes, SQ_WAIT_ANY 0.44-0.49, MFMA 0.08-0.12 busy).
+//   * waves 4-7 are LOADERS (LDS-DMA only: activation pieces of 4 rows x 256 B, the 1-KiB native weight tiles, one
+//     1-KiB row of (scale, zero) words per 128-k phase), counted vmcnt, one barrier per phase, phases walked cyclically
+//     from (7 b) % count in workgroup b;
+//   * waves 0-3 are CONSUMERS, one per SIMD, each owning NT 16-column tiles x all M rows: an activation fragment feeds
+//     NT MFMAs (NT = 4: a quarter of the fragment reads per flop), and the workgroup's 64 NT columns share one pass
+//     over the activations -- at fp16/bf16 activations against int4 weights the ACTIVATION block is most of what a CU
+//     ingests ((M x 256 B) per phase against NT x 4 KiB of weights), so wide column blocks + split-K beat 128-column
+//     blocks (w4_xw_plan);
+//   * the epilogue goes through LDS: whole-row stores of the fp32 slab tile or of the T-typed output by all 8 waves.
+// Dequant, MFMA operands and the per-element accumulation order over a workgroup's phases are those of
+// w4a16_xs_kernel up to the rotation of the phase walk (fp32 sums of the same terms in another order).
+#ifdef MI_TUNING
+// diagnostic build only (MI_W4_STAMPS=1): per (workgroup, wave) cycle sums of w4a16_xw_kernel's phase segments
+__device__ unsigned long long mi_w4_stamps[512 * 12 * 8];
+extern "C" int mi_debug_w4_stamps(unsigned long long* host_out, int clear) {
+  if (clear) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(mi_w4_stamps)) != hipSuccess) return -1;
+    return hipMemset(d, 0, sizeof(mi_w4_stamps)) == hipSuccess ? 0 : -1;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi_w4_stamps), sizeof(mi_w4_stamps)) == hipSuccess ? 0 : -1;
+}
+static int w4_stamps_on() {
+  static const int v = mi_tune("MI_W4_STAMPS", 0);
+  return v;
+}
+#endif
+template <int MT, int NT> struct W4XW {
+  static constexpr int ROWS = MT * 16, WR = 64 * NT;
+  static constexpr int XBYTES = ROWS * 256, WBYTES = 4 * NT * 1024, ZBYTES = 1024;
+  static constexpr int STAGE = XBYTES + WBYTES + ZBYTES;
+  static constexpr int TILE = ROWS * (WR * 4 + 16);                      // staged fp32 output tile
+  static constexpr int R = (160 * 1024 / STAGE) >= 4 ? 4 : (160 * 1024 / STAGE);   // ring stages
+  static constexpr int LDS = R * STAGE > TILE ? R * STAGE : TILE;
+  static_assert(R >= 3 && LDS <= 160 * 1024, "ring of at least 3 stages within the CU's LDS");
+};
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* __restrict__ slab, int S,
+                                                       int phases_per_wg, int dbg) {
+  typedef typename Elem<T>::vec8 vec8;
+  typedef W4XW<MT, NT> C;
+  constexpr int ROWS = C::ROWS, WR = C::WR, XBYTES = C::XBYTES, WBYTES = C::WBYTES, STAGE = C::STAGE, R = C::R;
+  constexpr int D = R - 1, NL = 4, NCW = 8;               // 8 consumer waves (two per SIMD) + 4 loader waves
+  constexpr int TPC = 4 * NT >= NCW ? 4 * NT / NCW : 1;   // 16-column tiles per consumer (NT = 1: consumers 4-7 idle)
+  constexpr int NWAVES = NCW + NL;
+  constexpr int XPIECES = ROWS / 4;                       // activation DMA pieces (4 rows x 256 B) per phase
+  constexpr int XL = XPIECES >= NL ? XPIECES / NL : 1;    // per loader (small M: loaders re-fetch a piece)
+  constexpr int WL = NT;                                  // weight tiles per loader (4 NT per workgroup)
+  constexpr int E = XL + WL + 1;                          // vmcnt entries per loader per phase (+ the zs row)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int sp = blockIdx.y;
+  const int64_t KB = p.K / 128;
+  const int64_t ph0 = (int64_t)sp * phases_per_wg;
+  const int64_t ph1 = min(KB, ph0 + phases_per_wg);
+  const int64_t col0 = (int64_t)blockIdx.x * WR;          // first output column of the workgroup
+  const uint32_t lds_base = lds_addr_of(smem);
+
+  f32x4 acc[TPC][MT];
+#pragma unroll
+  for (int tn = 0; tn < TPC; ++tn)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[tn][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool has_tiles = wave * TPC < 4 * NT;             // (consumer waves only)
+
+  if (wave >= NCW) {
+    // ---------------------------------------------------------------- loaders
+    const int ld = wave - NCW;
+    const int drow = lane >> 4, dslot = lane & 15;
+    const int64_t ntiles = p.N / 16;
+    const int64_t nphw = ph1 - ph0;
+    const int64_t rot = nphw > 0 ? ((int64_t)blockIdx.x * 7) % nphw : 0;
+    const uint4* wsrc[WL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int64_t nt = min((int64_t)blockIdx.x * (4 * NT) + ld * WL + i, ntiles - 1);
+      wsrc[i] = (const uint4*)p.qw + nt * KB * 64 + lane;
+    }
+    const T* xsrc[XL];
+    uint32_t xdst[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int rr = ((ld * XL + i) % XPIECES) * 4;
+      const int row = rr + drow;
+      xsrc[i] = (const T*)p.x + min((int64_t)row, p.M - 1) * p.ldx + (dslot ^ (row & 15)) * 8;
+      xdst[i] = lds_base + rr * 256;
+    }
+    const int64_t zcol = min(col0 + lane * 4, p.N - 4);   // (scale, zero) words of 4 columns per lane
+    auto issue = [&](int64_t ph) __attribute__((always_inline)) {
+      const uint32_t st = (uint32_t)((ph - ph0) % R) * STAGE;
+      int64_t kph = ph + rot;
+      kph = kph >= ph1 ? kph - nphw : kph;
+#pragma unroll
+      for (int i = 0; i < XL; ++i) glds16(xsrc[i] + kph * 128, xdst[i] + st);
+#pragma unroll
+      for (int i = 0; i < WL; ++i) glds16(wsrc[i] + kph * 64, lds_base + st + XBYTES + (ld * WL + i) * 1024);
+      glds16(p.zs + ((kph * 128) / p.group) * p.N + zcol, lds_base + st + XBYTES + WBYTES);
+    };
+    static_assert(D >= 2 && D <= 3, "the wait enumerates up to 2 phases in flight behind the awaited one");
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (ph0 + d < ph1) issue(ph0 + d);
+#ifdef MI_TUNING
+    unsigned long long t_iss = 0, t_wait = 0, t_bar = 0;
+#endif
+    for (int64_t ph = ph0; ph < ph1; ++ph) {
+#ifdef MI_TUNING
+      const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      const int64_t after = min((int64_t)(D - 1), ph1 - 1 - ph);   // phases issued after ph may stay in flight
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MI_TUNING
+      const unsigned long long tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      __builtin_amdgcn_s_barrier();                      // phase ph published; the consumers are done with ph-1
+#ifdef MI_TUNING
+      const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
+#ifdef MI_TUNING
+      if (dbg) { const unsigned long long td = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; t_bar += tc - tb; t_iss += td - tc; }
+#endif
+    }
+#ifdef MI_TUNING
+    if (dbg && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+      unsigned long long* o = mi_w4_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+      o[0] += t_iss; o[1] += t_wait; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
+    }
+#endif
+    __builtin_amdgcn_s_barrier();                        // (the consumers' "LDS may be reused" barrier)
+  } else {
+    // ---------------------------------------------------------------- consumers
+#ifdef MI_TUNING
+    unsigned long long t_cmp = 0, t_bar = 0, t_prev = 0;
+    const unsigned long long t_k0 = dbg ? __builtin_amdgcn_s_memtime() : 0, r_k0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
+    for (int64_t ph = ph0; ph < ph1; ++ph) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MI_TUNING
+      const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+      __builtin_amdgcn_s_barrier();                      // phase ph landed (the loaders waited for it)
+#ifdef MI_TUNING
+      if (dbg) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); if (t_prev) t_cmp += ta - t_prev; t_bar += tb - ta; t_prev = tb; }
+#endif
+      const char* xb = smem + ((ph - ph0) % R) * STAGE;
+      const char* wb = xb + XBYTES;
+      if (!has_tiles) continue;
+      uint32_t ww[TPC][4], zsv[TPC];
+#pragma unroll
+      for (int tn = 0; tn < TPC; ++tn) {
+        const int tile = wave * TPC + tn;
+        const uint4 wv = *(const uint4*)(wb + tile * 1024 + lane * 16);
+        ww[tn][0] = wv.x; ww[tn][1] = wv.y; ww[tn][2] = wv.z; ww[tn][3] = wv.w;
+        zsv[tn] = *(const uint32_t*)(wb + WBYTES + (tile * 16 + r16) * 4);
+      }
+      // Software pipeline over the four 32-k steps of the phase, in SOURCE order behind scheduling fences: after each
+      // MFMA of step s comes one quarter of a weight fragment of step s + 1 (4-5 VALU), the activation fragments of
+      // step s + 1 are requested in front of the MFMAs of step s.  A wave issues in order: left to the scheduler, each
+      // step's dequant (16-24 VALU per tile) sits in one block in front of its MFMAs and the matrix pipe idles
+      // meanwhile (stamps: 1600-2300 cycles per phase for 512 cycles of MFMA per wave).
+      typename DeqQ<T>::Zs zq[TPC];
+#pragma unroll
+      for (int tn = 0; tn < TPC; ++tn) zq[tn] = DeqQ<T>::zs(zsv[tn]);
+      uint4 xr[2][MT];
+      uint32_t wfr[2][TPC][4];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xr[0][t] = *(const uint4*)(xb + (t * 16 + r16) * 256 + ((q ^ r16) * 16));
+#pragma unroll
+      for (int tn = 0; tn < TPC; ++tn) {
+        wfr[0][tn][0] = DeqQ<T>::template part<0>(ww[tn][0], zq[tn]);
+        wfr[0][tn][1] = DeqQ<T>::template part<1>(ww[tn][0], zq[tn]);
+        wfr[0][tn][2] = DeqQ<T>::template part<2>(ww[tn][0], zq[tn]);
+        wfr[0][tn][3] = DeqQ<T>::template part<3>(ww[tn][0], zq[tn]);
+      }
+      constexpr int NM = TPC * MT, NP = TPC * 4;                          // MFMAs / fragment quarters per step
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 3) {
+          const int o = (((s + 1) * 4 + q) ^ r16) * 16;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) xr[nxt][t] = *(const uint4*)(xb + (t * 16 + r16) * 256 + o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+          const int t = j / TPC, tn = j % TPC;
+          const vec8 wfv = __builtin_bit_cast(vec8, u32x4{wfr[cur][tn][0], wfr[cur][tn][1], wfr[cur][tn][2], wfr[cur][tn][3]});
+          acc[tn][t] = Elem<T>::mfma16(wfv, __builtin_bit_cast(vec8, xr[cur][t]), acc[tn][t]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s < 3) {
+#pragma unroll
+            for (int pi = j * NP / NM; pi < (j + 1) * NP / NM; ++pi) {   // this MFMA's share of the next step's quarters
+              const int ptn = pi / 4;
+              const uint32_t wn = ww[ptn][s + 1];
+              switch (pi & 3) {
+                case 0: wfr[nxt][ptn][0] = DeqQ<T>::template part<0>(wn, zq[ptn]); break;
+                case 1: wfr[nxt][ptn][1] = DeqQ<T>::template part<1>(wn, zq[ptn]); break;
+                case 2: wfr[nxt][ptn][2] = DeqQ<T>::template part<2>(wn, zq[ptn]); break;
+                default: wfr[nxt][ptn][3] = DeqQ<T>::template part<3>(wn, zq[ptn]); break;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+#ifdef MI_TUNING
+    if (dbg && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+      unsigned long long* o = mi_w4_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+      o[0] += t_cmp; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
+      o[4] += __builtin_amdgcn_s_memtime() - t_k0; o[5] += __builtin_amdgcn_s_memrealtime() - r_k0;
+    }
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // every stage consumed: the epilogue may reuse LDS
+  }
+
+  // ------------------------------------------------------------------ epilogue through LDS: [ROWS][WR] fp32, rows
+  // padded to 4 WR + 16 bytes (conflict-free ds_write_b128), then whole-row stores by all 8 waves
+  constexpr int TP = WR * 4 + 16;
+  const bool to_slab = S > 1;
+  if (wave < NCW && has_tiles) {
+#pragma unroll
+    for (int tn = 0; tn < TPC; ++tn) {
+      const int cb = (wave * TPC + tn) * 16 + 4 * q;       // block column of the lane's 4 values
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!to_slab && p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (float)((const T*)p.bias)[min(col0 + cb + r, p.N - 1)];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        f32x4 v = acc[tn][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+        *(f32x4*)(smem + (t * 16 + r16) * TP + cb * 4) = v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (to_slab) {
+    float* sbp = slab + (int64_t)sp * p.M * p.N + col0;
+    constexpr int LPR = WR / 4, RPW = 64 / LPR;           // lanes per row (16 B each), rows per wave instruction
+#pragma unroll
+    for (int i = 0; i < (ROWS + NWAVES * RPW - 1) / (NWAVES * RPW); ++i) {
+      const int row = (i * NWAVES + wave) * RPW + lane / LPR, c = lane % LPR;
+      if (row < ROWS && row < p.M && col0 + c * 4 < p.N)
+        *(f32x4*)(sbp + (int64_t)row * p.N + c * 4) = *(const f32x4*)(smem + row * TP + c * 16);
+    }
+  } else {
+    T* op = (T*)p.out + col0;
+    constexpr int LPR = WR / 8, RPW = 64 / LPR;           // 8 columns per lane
+#pragma unroll
+    for (int i = 0; i < (ROWS + NWAVES * RPW - 1) / (NWAVES * RPW); ++i) {
+      const int row = (i * NWAVES + wave) * RPW + lane / LPR, c = lane % LPR;
+      if (row < ROWS && row < p.M && col0 + c * 8 < p.N) {
+        const f32x4 a = *(const f32x4*)(smem + row * TP + c * 32), b = *(const f32x4*)(smem + row * TP + c * 32 + 16);
+        *(uint4*)(op + (int64_t)row * p.ldo + c * 8) =
+            make_uint4(pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3]));
+      }
     }
   }
 }
@@ -601,6 +911,59 @@ static void w4_plan(int64_t N, int64_t K, int* S, int* ppw) {
   *S = (int)cdiv64(nph, per);
 }
 
+// Plan of the role kernel: column block of 64 NT columns (NT = 4, 2, 1) and split-K factor S.  Per 128-k phase a
+// workgroup ingests the activation block (rows x 256 B) + NT x 4 KiB of weights + 1 KiB of (scale, zero) words at
+// ~45 GB/s per CU (tools/xd_stamps.py on the FP8 kernel: the LDS-DMA issue rate of a CU), and every slab byte is written
+// and read again (~4.5 TB/s each way): the cheapest (NT, S) by that model, S chosen to fill one round of 256 CUs.
+// C4 (M = 64): gate_up 22016 x 4096 -> NT 4, S 3; qkv 12288 x 4096 -> NT 4 / S 5 or NT 2 / S 2; o, down -> NT 2 or 1.
+static bool w4_xw_plan(int64_t M, int64_t N, int64_t K, int64_t group, int* S, int* ppw, int* nt_out) {
+  static const int enable = mi_tune("MI_W4_XW", 1);
+  if (!enable || M > 128 || K % 128 != 0 || group % 128 != 0 || N % 64 != 0) return false;
+  const int64_t nph = K / 128, rows = M <= 16 ? 16 : M <= 32 ? 32 : M <= 64 ? 64 : 128;
+  double best = 0;
+  bool found = false;
+  for (int nt = 4; nt >= 1; nt >>= 1) {
+    const int64_t wr = 64 * nt;
+    if (N % wr != 0) continue;
+    if (rows * 256 + nt * 4096 + 1024 > 160 * 1024 / 3) continue;         // three stages must fit
+    const int64_t nblk = N / wr;
+    int64_t want = nblk >= 200 ? 1 : 256 / nblk;
+    if (want < 1) want = 1;
+    if (want > nph) want = nph;
+    const int64_t per = cdiv64(nph, want), s = cdiv64(nph, per);
+    const double ingest_us = (double)(rows * 256 + nt * 4096 + 1024) * (double)per / 45e3;
+    const double slab_us = s > 1 ? 2.0 * (double)s * (double)M * (double)N * 4.0 / 4.5e6 : 0.0;
+    const double cost = (double)cdiv64(nblk * s, 256) * ingest_us + slab_us;
+    if (!found || cost < best) { best = cost; found = true; *S = (int)s; *ppw = (int)per; *nt_out = nt; }
+  }
+  return found;
+}
+
+template <typename T, int MT, int NT>
+static void launch_w4_xw_nt(const W4Params& p, float* slab, int S, int ppw, hipStream_t st) {
+  dim3 grid((unsigned)(p.N / (64 * NT)), (unsigned)S);
+#ifdef MI_TUNING
+  const int dbg = w4_stamps_on();
+#else
+  const int dbg = 0;
+#endif
+  w4a16_xw_kernel<T, MT, NT><<<grid, 768, W4XW<MT, NT>::LDS, st>>>(p, slab, S, ppw, dbg);
+}
+template <typename T, int MT>
+static void launch_w4_xw(const W4Params& p, float* slab, int S, int ppw, int nt, hipStream_t st, bool reduce) {
+  if (nt == 4) launch_w4_xw_nt<T, MT, 4>(p, slab, S, ppw, st);
+  else if (nt == 2) launch_w4_xw_nt<T, MT, 2>(p, slab, S, ppw, st);
+  else launch_w4_xw_nt<T, MT, 1>(p, slab, S, ppw, st);
+  if (S > 1 && reduce) w4_reduce_kernel<T><<<(unsigned)cdiv64(p.M * (p.N / 4), 256), 256, 0, st>>>(p, slab, S);
+}
+template <typename T>
+static void launch_w4_xw_m(const W4Params& p, float* slab, int S, int ppw, int nt, hipStream_t st, bool reduce) {
+  if (p.M <= 16) launch_w4_xw<T, 1>(p, slab, S, ppw, nt, st, reduce);
+  else if (p.M <= 32) launch_w4_xw<T, 2>(p, slab, S, ppw, nt, st, reduce);
+  else if (p.M <= 64) launch_w4_xw<T, 4>(p, slab, S, ppw, nt, st, reduce);
+  else launch_w4_xw<T, 8>(p, slab, S, ppw, nt, st, reduce);
+}
+
 #define W4_CHUNK_MAX_M 512   // batches of 129..512 rows: the decode kernel once per 128-row chunk (above: the tile kernel)
 extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
@@ -609,9 +972,13 @@ extern "C" int64_t mi_w4a16_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K
     return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
   }
   if (M > 128) M = 128;
-  int S, ppw;
+  int S, ppw, nt;
   w4_plan(N, K, &S, &ppw);
-  return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+  int64_t need = S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+  // the role kernel's plan (group size unknown here: assume it applies; its slabs are never larger than 8 x M x N x 4)
+  if (w4_xw_plan(M, N, K, 128, &S, &ppw, &nt) && S > 1 && (int64_t)S * M * N * (int64_t)sizeof(float) > need)
+    need = (int64_t)S * M * N * (int64_t)sizeof(float);
+  return need;
 }
 
 template <typename T, int MT>
@@ -640,7 +1007,14 @@ static bool try_w4_xs(const W4Params& p, void* workspace, int64_t workspace_byte
     }
     return true;
   }
-  int S, ppw;
+  int S, ppw, nt;
+  if ((((uintptr_t)p.zs | (uintptr_t)p.out) & 15) == 0 && p.ldo % 8 == 0 && w4_xw_plan(p.M, p.N, p.K, p.group, &S, &ppw, &nt)) {
+    const int64_t need_xw = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
+    if (need_xw <= workspace_bytes && (need_xw == 0 || workspace)) {
+      launch_w4_xw_m<T>(p, (float*)workspace, S, ppw, nt, st, true);
+      return true;
+    }
+  }
   w4_plan(p.N, p.K, &S, &ppw);
   const int64_t need = S > 1 ? (int64_t)S * p.M * p.N * (int64_t)sizeof(float) : 0;
   if (need > workspace_bytes || (need > 0 && !workspace)) {
