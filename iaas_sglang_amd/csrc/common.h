@@ -94,6 +94,18 @@ template <int N> __device__ __forceinline__ float row_bcast(float v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// SiLU in fp32, g / (1 + e^-g) as g * rcp(1 + 2^(-g log2 e)): v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul instead of the
+// ~37 instructions of expf() + an IEEE division.  Every SiLU of the library goes through this one function, so the
+// fused forms stay bit-identical to the unfused kernels; against the reference's activation.py:56-58 (torch's fp32
+// silu, then one rounding to the model dtype) the fp32 value differs by a few ulp (|g| * 6e-8 relative from the scaled
+// exponent, 1 ulp each from v_exp_f32 / v_rcp_f32), i.e. far inside the half-ulp of bf16 / fp16 it is rounded to
+// (tests/test_elementwise_gpu.py::test_silu_and_mul_golden).  Large negative g: 2^(+big) = inf, rcp = 0, g * 0 = -0.
+// Measured: the SiLU epilogue of the decode gate_up GEMM (16 elements per lane on all 8 waves) and of the prefill tile
+// GEMM (~10 us per 256 x 256 tile) were issue-bound on this arithmetic.
+__device__ __forceinline__ float silu_f32(float g) {
+  return g * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Tuning constants.  The shipped library has them compiled in; a developer build (`make TUNING=1`, -DMI_TUNING) lets

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ x, 
     unpack8f<T>(*(const uint4*)(x + r * ldx + c * 8), a);
     unpack8f<T>(*(const uint4*)(x + r * ldx + I + c * 8), b);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = rnd<T>(a[j] / (1.f + expf(-a[j]))) * b[j];
+    for (int j = 0; j < 8; ++j) o[j] = rnd<T>(silu_f32(a[j])) * b[j];
     if (out) *(uint4*)(out + r * ldo + c * 8) = pack8f<T>(o);
     if (q_out) {
 #pragma unroll

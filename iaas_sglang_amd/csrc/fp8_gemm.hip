@@ -308,7 +308,7 @@ __device__ __forceinline__ void xs_epilogue(const GemmParams& p, float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float g = acc[t][r];
-        o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+        o[r] = round_to<OutT>(round_to<OutT>(silu_f32(g)) * u[r]);
         o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
       }
       uint32_t w = 0;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float g = g4[r];
-            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u4[r]);
+            o[r] = round_to<OutT>(round_to<OutT>(silu_f32(g)) * u4[r]);
             o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
           }
           w[k] = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_xw_kernel(const GemmParams p, fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float g = acc[tn][t][r];
-          o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u[r]);
+          o[r] = round_to<OutT>(round_to<OutT>(silu_f32(g)) * u[r]);
           o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
         }
         uint32_t w = 0;
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float g = up ? o2[r] : own[r], u = up ? own[r] : o2[r];
-            o[r] = round_to<OutT>(round_to<OutT>(g / (1.f + expf(-g))) * u);
+            o[r] = round_to<OutT>(round_to<OutT>(silu_f32(g)) * u);
             o[r] = fmaxf(fminf(o[r] * qinv, 448.0f), -448.0f);
           }
           uint32_t w = 0;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float gv = rndT<T>(g[j] * sa[0] * sb[0]), uv = rndT<T>(u[j] * sa[0] * sb[0]);
-      o[j] = rndT<T>(rndT<T>(gv / (1.f + expf(-gv))) * uv);
+      o[j] = rndT<T>(rndT<T>(silu_f32(gv)) * uv);
     }
     *(uint2*)(q_out + r * I + c * 8) = quant8g(o, qinv);
   }
