@@ -308,7 +308,7 @@ class LlamaStack:
         logits = torch.matmul(x, self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)
 
-    def forward_decode_two_batch(self, hidden, positions, fbs, backends, streams, custom_ars=None):
+    def forward_decode_two_batch(self, hidden, positions, fbs, backends, streams, custom_ars=None, return_hidden=False):
         """Two-micro-batch overlap of a decode step (the behaviour of two_batch_overlap.py:361-615 for a dense model):
         the batch is split into halves A and B (`fbs`, `backends`: one ForwardBatch + attention backend each, rows
         [0, nA) and [nA, nA + nB) of `hidden`), each half runs the whole fused layer sequence on its own HIP stream,
@@ -353,6 +353,8 @@ class LlamaStack:
             cur.wait_stream(st)
         for o in outs:
             o.record_stream(cur)       # allocated on a side stream, consumed on the joined one
+        if return_hidden:              # final-norm output of the whole batch (tests capture the step without the lm_head)
+            return torch.cat(outs, dim=0)
         logits = torch.matmul(torch.cat(outs, dim=0), self.lm_head.t())
         return tensor_model_parallel_all_gather(logits, self.tp, self.group)
 

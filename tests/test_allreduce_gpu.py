@@ -258,6 +258,42 @@ def _tbo_worker(rank, world, port, out):
         if not same:
             print(f"[rank {rank}] two-batch TP step: max diff {(got.float().cpu() - want).abs().max()}", flush=True)
         ok = ok and same and not any(c.timed_out() for c in cas) and bool(torch.isfinite(want).all())
+        # the configuration bench.py times for world > 1 (--tbo auto): the two-branch step captured into ONE hipGraph
+        # inside both communicators' capture() contexts, replayed with new inputs; both ranks replay in lock-step (the
+        # all-reduce kernels of the two branches spin on their peers), every replay bit-identical to the eager serial step
+        import contextlib
+        for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+            b.copy_(b0)
+        hidden.copy_(hidden0)
+        stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], streams, cas, return_hidden=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with contextlib.ExitStack() as es:
+            for c in cas:
+                es.enter_context(c.capture())
+            with torch.cuda.graph(g):
+                got_h = stack.forward_decode_two_batch(hidden, fb.positions, halves, [backend, backend_b], streams, cas,
+                                                       return_hidden=True)
+        for trial in range(3):
+            h_in = torch.randn(B, shape.hidden, generator=torch.Generator().manual_seed(10 + trial)).to(dtype).to(dev)
+            for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+                b.copy_(b0)
+            hidden.copy_(h_in)
+            backend.init_forward_metadata(fb)
+            want_h = stack.forward_decode_fused(hidden, fb.positions, fb, backend, return_hidden=True).clone()
+            for b, b0 in zip(pool.k_buffer + pool.v_buffer, kv0):
+                b.copy_(b0)
+            hidden.copy_(h_in)
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            same = torch.equal(got_h, want_h)
+            if not same:
+                print(f"[rank {rank}] captured two-batch TP step, replay {trial}: max diff "
+                      f"{(got_h.float() - want_h.float()).abs().max()}", flush=True)
+            ok = ok and same and not any(c.timed_out() for c in cas)
     finally:
         for c in cas:
             c.close()
@@ -267,7 +303,8 @@ def _tbo_worker(rank, world, port, out):
 
 def test_tp2_two_batch_overlap_matches_serial_step():
     """C5's overlap on a TP=2 decode step (two processes on one GPU): each micro-batch on its own stream with its own
-    native all-reduce communicator, against the serial fused step -- bit-identical logits."""
+    native all-reduce communicator, against the serial fused step -- bit-identical logits; then the same two-branch
+    step captured into one hipGraph under both communicators' capture() and replayed three times with new inputs."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_tbo_worker, args=(2, _free_port(), out), nprocs=2, join=True)
