@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_hotpath.so")
 
-ABI_VERSION = 7          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
+ABI_VERSION = 8          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
 MI_BF16, MI_FP16, MI_F32 = 0, 1, 2
 MI_SCALE_TENSOR, MI_SCALE_ROW = 0, 1
 MI_W4_AWQ, MI_W4_GPTQ = 0, 1
@@ -59,6 +59,10 @@ SIGNATURES = {
     "mi_w4_repack": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
     "mi_w4a16_gemm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mi_w4a16_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "mi_w4a16_fused_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "mi_w4a16_gemm_add_rmsnorm": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _int, _p, _i64, _p]),
+    "mi_w4a16_gemm_rope_kvwrite": (_int, [_p] * 9 + [_i64] * 10 + [_int, _p, _i64, _p]),
+    "mi_w4a16_gemm_silu_mul": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mi_ar_shared_bytes": (_i64, [_i64]),
     "mi_ar_alloc_shared": (_int, [_i64, C.POINTER(C.c_void_p)]),
     "mi_ar_free_shared": (_int, [_p]),

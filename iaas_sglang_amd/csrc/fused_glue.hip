@@ -250,12 +250,13 @@ static int slab_rope_kvwrite(const float* slab, int S, const float* scale_a, con
 
 // ------------------------------------------------ slabs (gate_up) -> SiLU(gate) * up -> fp8
 // == fp8_gemm reduce epilogue, SiluAndMul.forward_native (activation.py:56-58), static per-tensor quant.
+// q_scale == nullptr: T-typed output (q_out points at T [M, I]): the 16-bit-activation form for the int4 linears
 template <typename T>
 __global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __restrict__ slab, int S,
                                                                 const float* __restrict__ sa, const float* __restrict__ sb,
                                                                 uint8_t* __restrict__ q_out, const float* __restrict__ q_scale,
                                                                 int64_t M, int64_t I) {
-  const float qs = *q_scale;
+  const float qs = q_scale ? *q_scale : 1.f;
   const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
   const int64_t vpr = I / 8, N = 2 * I;
   for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < M * vpr; gid += (int64_t)gridDim.x * 256) {
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256) void slab_silu_mul_fp8_kernel(const float* __r
       const float gv = rndT<T>(g[j] * sa[0] * sb[0]), uv = rndT<T>(u[j] * sa[0] * sb[0]);
       o[j] = rndT<T>(rndT<T>(silu_f32(gv)) * uv);
     }
-    *(uint2*)(q_out + r * I + c * 8) = quant8g(o, qinv);
+    if (q_scale) *(uint2*)(q_out + r * I + c * 8) = quant8g(o, qinv);
+    else *(uint4*)((T*)q_out + r * I + c * 8) = pack8g<T>(o);
   }
 }
 
@@ -393,6 +395,93 @@ extern "C" int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const f
     slab_silu_mul_fp8_kernel<bf16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, scale_a, scale_b, (uint8_t*)q_out, q_scale, M, I);
   else
     slab_silu_mul_fp8_kernel<f16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, scale_a, scale_b, (uint8_t*)q_out, q_scale, M, I);
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+
+// ============================================================================ int4 (AWQ / GPTQ) linears fused with
+// their consumer: the same three consumer kernels on the slabs of w4a16_xw_kernel, 16-bit activations in and out (unit
+// scales: x = round_T(sum of the slabs), exactly what w4_reduce_kernel gives without a bias).  The C4 decode layer
+// (Llama-2-7B AWQ) drops from 19 launches to 9: norm (first layer) | qkv + rope + kv-write | attention, merge |
+// o + add + norm | gate_up + silu*mul | down + add + norm.  Bit-identical to the unfused sequence
+// (tests/test_fused_gpu.py::test_w4_fused_*).
+MI_INTERNAL int mi_w4a16_plan_splits(int64_t M, int64_t N, int64_t K, int64_t group);
+MI_INTERNAL int mi_w4a16_gemm_partial(const void* x, const void* qw_native, const void* zs_native, float* slabs, int64_t M,
+                                     int64_t N, int64_t K, int64_t group, int64_t ldx, int dtype, void* stream);
+__device__ float mi_unit_scale = 1.0f;
+static const float* unit_scale_ptr() {
+  static const float* p = nullptr;
+  if (!p) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(mi_unit_scale)) == hipSuccess) p = (const float*)d;
+  }
+  return p;
+}
+extern "C" int64_t mi_w4a16_fused_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t group_size) {
+  if (M <= 0 || M > 128) return 0;
+  const int S = mi_w4a16_plan_splits(M, N, K, group_size > 0 ? group_size : K);
+  return S > 0 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+}
+#define W4_FUSED_PROLOGUE(NAME)                                                                          \
+  MI_CHECK_ARG(M > 0 && N > 0 && K > 0 && x && qw_native && zs_native);                                  \
+  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);                                                    \
+  if (group_size <= 0) group_size = K;                                                                   \
+  const int S = M <= 128 ? mi_w4a16_plan_splits(M, N, K, group_size) : 0;                                \
+  if (S <= 0) MI_FAIL(MI_ERR_UNSUPPORTED, NAME ": decode shapes only (M <= 128, K %% 128 == 0, N %% 64 == 0, group %% 128 == 0)"); \
+  const int64_t need = (int64_t)S * M * N * (int64_t)sizeof(float);                                      \
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))                               \
+    MI_FAIL(MI_ERR_INVALID, NAME ": workspace of mi_w4a16_fused_workspace_bytes() = %lld bytes needed", (long long)need); \
+  const float* one = unit_scale_ptr();                                                                   \
+  if (!one) MI_FAIL(MI_ERR_LAUNCH, NAME ": device constant not available")
+
+extern "C" int mi_w4a16_gemm_add_rmsnorm(const void* x, const void* qw_native, const void* zs_native, void* residual,
+                                         const void* norm_weight, void* out, int64_t M, int64_t N, int64_t K,
+                                         int64_t group_size, int64_t ldx, float eps, int dtype, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  W4_FUSED_PROLOGUE("mi_w4a16_gemm_add_rmsnorm");
+  MI_CHECK_ARG(norm_weight && out);
+  if (N % 8 != 0 || N > 256 * 8 * 8) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_w4a16_gemm_add_rmsnorm: N must be a multiple of 8, <= 16384");
+  const int rc = mi_w4a16_gemm_partial(x, qw_native, zs_native, (float*)workspace, M, N, K, group_size, ldx, dtype, stream);
+  if (rc != MI_OK) return rc;
+  return slab_add_rmsnorm_fp8((const float*)workspace, S, one, one, residual, norm_weight, nullptr, nullptr, out, M, N, eps,
+                              dtype, stream);
+}
+
+extern "C" int mi_w4a16_gemm_rope_kvwrite(const void* x, const void* qw_native, const void* zs_native,
+                                          const int64_t* positions, const float* cos_sin_cache, void* q_out, void* k_cache,
+                                          void* v_cache, const int64_t* loc, int64_t M, int64_t num_q_heads,
+                                          int64_t num_kv_heads, int64_t head_dim, int64_t K, int64_t group_size, int64_t ldx,
+                                          int64_t ldq, int64_t cache_stride_k, int64_t cache_stride_v, int dtype,
+                                          void* workspace, int64_t workspace_bytes, void* stream) {
+  const int64_t N = (num_q_heads + 2 * num_kv_heads) * head_dim;
+  W4_FUSED_PROLOGUE("mi_w4a16_gemm_rope_kvwrite");
+  MI_CHECK_ARG(positions && cos_sin_cache && q_out && k_cache && v_cache && loc && num_q_heads > 0 && num_kv_heads > 0);
+  MI_CHECK_ARG(((uintptr_t)cos_sin_cache & 15) == 0);
+  if (head_dim % 16 != 0 || ldq % 8 || cache_stride_k % 8 || cache_stride_v % 8)
+    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_w4a16_gemm_rope_kvwrite: head_dim %% 16 and 16-byte aligned rows required");
+  const int rc = mi_w4a16_gemm_partial(x, qw_native, zs_native, (float*)workspace, M, N, K, group_size, ldx, dtype, stream);
+  if (rc != MI_OK) return rc;
+  return slab_rope_kvwrite((const float*)workspace, S, one, one, positions, cos_sin_cache, q_out, k_cache, v_cache, loc, M,
+                           num_q_heads, num_kv_heads, head_dim, ldq, cache_stride_k, cache_stride_v, dtype, stream);
+}
+
+extern "C" int mi_w4a16_gemm_silu_mul(const void* x, const void* qw_native, const void* zs_native, void* out, int64_t M,
+                                      int64_t I, int64_t K, int64_t group_size, int64_t ldx, int dtype, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(I > 0 && out);
+  const int64_t N = 2 * I;
+  W4_FUSED_PROLOGUE("mi_w4a16_gemm_silu_mul");
+  if (I % 8 != 0 || ((uintptr_t)out & 15)) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_w4a16_gemm_silu_mul: I %% 8 == 0 and a 16-byte aligned output required");
+  const int rc = mi_w4a16_gemm_partial(x, qw_native, zs_native, (float*)workspace, M, N, K, group_size, ldx, dtype, stream);
+  if (rc != MI_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = M * (I / 8);
+  const unsigned blocks = (unsigned)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  if (dtype == MI_BF16)
+    slab_silu_mul_fp8_kernel<bf16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, one, one, (uint8_t*)out, nullptr, M, I);
+  else
+    slab_silu_mul_fp8_kernel<f16_t><<<blocks, 256, 0, st>>>((const float*)workspace, S, one, one, (uint8_t*)out, nullptr, M, I);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -411,7 +411,7 @@ template <int MT, int NT> struct W4XW {
 
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* __restrict__ slab, int S,
-                                                       int phases_per_wg, int dbg) {
+                                                       int phases_per_wg, int dbg /* bit 0: stamps, bit 1: slab even when S == 1 */) {
   typedef typename Elem<T>::vec8 vec8;
   typedef W4XW<MT, NT> C;
   constexpr int ROWS = C::ROWS, WR = C::WR, XBYTES = C::XBYTES, WBYTES = C::WBYTES, STAGE = C::STAGE, R = C::R;
@@ -482,26 +482,26 @@ __global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* 
 #endif
     for (int64_t ph = ph0; ph < ph1; ++ph) {
 #ifdef MI_TUNING
-      const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long ta = (dbg & 1) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
       const int64_t after = min((int64_t)(D - 1), ph1 - 1 - ph);   // phases issued after ph may stay in flight
       if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
       else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MI_TUNING
-      const unsigned long long tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long tb = (dbg & 1) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
       __builtin_amdgcn_s_barrier();                      // phase ph published; the consumers are done with ph-1
 #ifdef MI_TUNING
-      const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long tc = (dbg & 1) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
       if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
 #ifdef MI_TUNING
-      if (dbg) { const unsigned long long td = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; t_bar += tc - tb; t_iss += td - tc; }
+      if (dbg & 1) { const unsigned long long td = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; t_bar += tc - tb; t_iss += td - tc; }
 #endif
     }
 #ifdef MI_TUNING
-    if (dbg && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+    if ((dbg & 1) && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
       unsigned long long* o = mi_w4_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
       o[0] += t_iss; o[1] += t_wait; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
     }
@@ -511,16 +511,16 @@ __global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* 
     // ---------------------------------------------------------------- consumers
 #ifdef MI_TUNING
     unsigned long long t_cmp = 0, t_bar = 0, t_prev = 0;
-    const unsigned long long t_k0 = dbg ? __builtin_amdgcn_s_memtime() : 0, r_k0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    const unsigned long long t_k0 = (dbg & 1) ? __builtin_amdgcn_s_memtime() : 0, r_k0 = (dbg & 1) ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
     for (int64_t ph = ph0; ph < ph1; ++ph) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef MI_TUNING
-      const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long ta = (dbg & 1) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
       __builtin_amdgcn_s_barrier();                      // phase ph landed (the loaders waited for it)
 #ifdef MI_TUNING
-      if (dbg) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); if (t_prev) t_cmp += ta - t_prev; t_bar += tb - ta; t_prev = tb; }
+      if (dbg & 1) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); if (t_prev) t_cmp += ta - t_prev; t_bar += tb - ta; t_prev = tb; }
 #endif
       const char* xb = smem + ((ph - ph0) % R) * STAGE;
       const char* wb = xb + XBYTES;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* 
       }
     }
 #ifdef MI_TUNING
-    if (dbg && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+    if ((dbg & 1) && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
       unsigned long long* o = mi_w4_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
       o[0] += t_cmp; o[2] += t_bar; o[3] += (unsigned long long)(ph1 - ph0);
       o[4] += __builtin_amdgcn_s_memtime() - t_k0; o[5] += __builtin_amdgcn_s_memrealtime() - r_k0;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(768) void w4a16_xw_kernel(const W4Params p, float* 
   // ------------------------------------------------------------------ epilogue through LDS: [ROWS][WR] fp32, rows
   // padded to 4 WR + 16 bytes (conflict-free ds_write_b128), then whole-row stores by all 8 waves
   constexpr int TP = WR * 4 + 16;
-  const bool to_slab = S > 1;
+  const bool to_slab = S > 1 || (dbg & 2);
   if (wave < NCW && has_tiles) {
 #pragma unroll
     for (int tn = 0; tn < TPC; ++tn) {
@@ -940,20 +940,21 @@ static bool w4_xw_plan(int64_t M, int64_t N, int64_t K, int64_t group, int* S, i
 }
 
 template <typename T, int MT, int NT>
-static void launch_w4_xw_nt(const W4Params& p, float* slab, int S, int ppw, hipStream_t st) {
+static void launch_w4_xw_nt(const W4Params& p, float* slab, int S, int ppw, hipStream_t st, bool partial) {
   dim3 grid((unsigned)(p.N / (64 * NT)), (unsigned)S);
 #ifdef MI_TUNING
-  const int dbg = w4_stamps_on();
+  const int dbg = w4_stamps_on() ? 1 : 0;
 #else
   const int dbg = 0;
 #endif
-  w4a16_xw_kernel<T, MT, NT><<<grid, 768, W4XW<MT, NT>::LDS, st>>>(p, slab, S, ppw, dbg);
+  w4a16_xw_kernel<T, MT, NT><<<grid, 768, W4XW<MT, NT>::LDS, st>>>(p, slab, S, ppw, dbg | (partial ? 2 : 0));
 }
+// `reduce`: sum the slabs with w4_reduce_kernel; false = the partial form (slabs even when S == 1, a fused consumer follows)
 template <typename T, int MT>
 static void launch_w4_xw(const W4Params& p, float* slab, int S, int ppw, int nt, hipStream_t st, bool reduce) {
-  if (nt == 4) launch_w4_xw_nt<T, MT, 4>(p, slab, S, ppw, st);
-  else if (nt == 2) launch_w4_xw_nt<T, MT, 2>(p, slab, S, ppw, st);
-  else launch_w4_xw_nt<T, MT, 1>(p, slab, S, ppw, st);
+  if (nt == 4) launch_w4_xw_nt<T, MT, 4>(p, slab, S, ppw, st, !reduce);
+  else if (nt == 2) launch_w4_xw_nt<T, MT, 2>(p, slab, S, ppw, st, !reduce);
+  else launch_w4_xw_nt<T, MT, 1>(p, slab, S, ppw, st, !reduce);
   if (S > 1 && reduce) w4_reduce_kernel<T><<<(unsigned)cdiv64(p.M * (p.N / 4), 256), 256, 0, st>>>(p, slab, S);
 }
 template <typename T>
@@ -1069,6 +1070,28 @@ extern "C" int mi_w4a16_gemm(const void* x, const void* qw_native, const void* z
     if (try_w4_xs<bf16_t>(p, workspace, workspace_bytes, st)) { MI_CHECK_LAUNCH(); return MI_OK; }
     if (perm) launch_w4<bf16_t, true>(p, st); else launch_w4<bf16_t, false>(p, st);
   }
+  MI_CHECK_LAUNCH();
+  return MI_OK;
+}
+
+// ---- split-K partial form for the fused consumers (fused_glue.hip): raw fp32 accumulators in `slabs` [S][M][N], no
+// epilogue.  Returns the split count S (>= 1), or 0 when the role kernel does not take the shape.
+MI_INTERNAL int mi_w4a16_plan_splits(int64_t M, int64_t N, int64_t K, int64_t group) {
+  int S, ppw, nt;
+  return w4_xw_plan(M, N, K, group, &S, &ppw, &nt) ? S : 0;
+}
+MI_INTERNAL int mi_w4a16_gemm_partial(const void* x, const void* qw_native, const void* zs_native, float* slabs, int64_t M,
+                                     int64_t N, int64_t K, int64_t group, int64_t ldx, int dtype, void* stream) {
+  MI_CHECK_ARG(x && qw_native && zs_native && slabs && M > 0 && M <= 128);
+  MI_CHECK_ARG((((uintptr_t)x | (uintptr_t)qw_native | (uintptr_t)zs_native | (uintptr_t)slabs) & 15) == 0 && ldx % 8 == 0);
+  int S, ppw, nt;
+  if (!w4_xw_plan(M, N, K, group, &S, &ppw, &nt)) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_w4a16_gemm_partial: shape not supported");
+  W4Params p;
+  p.x = x; p.qw = (const uint32_t*)qw_native; p.zs = (const uint32_t*)zs_native; p.perm = nullptr; p.bias = nullptr;
+  p.out = nullptr; p.M = M; p.N = N; p.K = K; p.group = group; p.ldx = ldx; p.ldo = N;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_FP16) launch_w4_xw_m<f16_t>(p, slabs, S, ppw, nt, st, false);
+  else launch_w4_xw_m<bf16_t>(p, slabs, S, ppw, nt, st, false);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

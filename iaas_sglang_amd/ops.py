@@ -723,3 +723,60 @@ def fp8_gemm_silu_mul(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor
                                        N // 2, K, a.stride(0), b_kn.stride(1), _DT[act_dtype], _ptr(ws), nbytes,
                                        _stream()), "mi_fp8_gemm_silu_mul_fp8")
     return q
+
+
+# ------------------------------------------------------------------ int4 linears fused with their consumer (decode)
+def _w4_fused_ws(M: int, N: int, K: int, group_size: int, device):
+    nbytes = lib.mi_w4a16_fused_workspace_bytes(M, N, K, int(group_size))
+    if nbytes <= 0:
+        raise ValueError(f"no fused int4 form for M={M} N={N} K={K} group={group_size} (decode shapes only)")
+    return _gemm_workspace(nbytes, device), nbytes
+
+
+def w4a16_fused_ok(M: int, N: int, K: int, group_size: int) -> bool:
+    return 0 < M <= 128 and lib.mi_w4a16_fused_workspace_bytes(M, N, K, int(group_size)) > 0
+
+
+def w4a16_gemm_add_rmsnorm(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, group_size: int,
+                           residual: Optional[torch.Tensor], norm_weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """out = rmsnorm(x.W (+ residual, updated in place)) * w, the int4 GEMM's slabs consumed by one kernel."""
+    assert x.dim() == 2 and x.stride(1) == 1 and norm_weight.dtype == x.dtype and norm_weight.numel() == N
+    M, K = x.shape
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.shape == (M, N) and residual.is_contiguous()
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    ws, nbytes = _w4_fused_ws(M, N, K, group_size, x.device)
+    check(lib.mi_w4a16_gemm_add_rmsnorm(_ptr(x), _ptr(qw), _ptr(zs), _ptr(residual), _ptr(norm_weight), _ptr(out), M, N, K,
+                                        int(group_size), x.stride(0), float(eps), _dt(x), _ptr(ws), nbytes, _stream()),
+          "mi_w4a16_gemm_add_rmsnorm")
+    return out
+
+
+def w4a16_gemm_rope_kvwrite(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, group_size: int, positions: torch.Tensor,
+                            cos_sin_cache: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor,
+                            num_q_heads: int, num_kv_heads: int, head_dim: int) -> torch.Tensor:
+    """qkv int4 linear + NeoX RoPE + KV-pool write; returns q [M, Hq*D]."""
+    assert x.dim() == 2 and x.stride(1) == 1 and k_cache.dtype == x.dtype == v_cache.dtype
+    M, K = x.shape
+    N = (num_q_heads + 2 * num_kv_heads) * head_dim
+    assert positions.dtype == torch.int64 and loc.dtype == torch.int64 and positions.numel() == M and loc.numel() == M
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim and cos_sin_cache.is_contiguous()
+    assert k_cache[0].is_contiguous() and v_cache[0].is_contiguous() and k_cache[0].numel() == num_kv_heads * head_dim
+    q = torch.empty(M, num_q_heads * head_dim, dtype=x.dtype, device=x.device)
+    ws, nbytes = _w4_fused_ws(M, N, K, group_size, x.device)
+    check(lib.mi_w4a16_gemm_rope_kvwrite(_ptr(x), _ptr(qw), _ptr(zs), _ptr(positions), _ptr(cos_sin_cache), _ptr(q),
+                                         _ptr(k_cache), _ptr(v_cache), _ptr(loc), M, num_q_heads, num_kv_heads, head_dim, K,
+                                         int(group_size), x.stride(0), q.stride(0), k_cache.stride(0), v_cache.stride(0),
+                                         _dt(x), _ptr(ws), nbytes, _stream()), "mi_w4a16_gemm_rope_kvwrite")
+    return q
+
+
+def w4a16_gemm_silu_mul(x: torch.Tensor, qw: torch.Tensor, zs: torch.Tensor, N: int, group_size: int) -> torch.Tensor:
+    """silu(gate) * up of the int4 gate_up linear ([gate | up] columns), [M, N / 2] in the activation dtype."""
+    assert x.dim() == 2 and x.stride(1) == 1 and N % 2 == 0
+    M, K = x.shape
+    out = torch.empty(M, N // 2, dtype=x.dtype, device=x.device)
+    ws, nbytes = _w4_fused_ws(M, N, K, group_size, x.device)
+    check(lib.mi_w4a16_gemm_silu_mul(_ptr(x), _ptr(qw), _ptr(zs), _ptr(out), M, N // 2, K, int(group_size), x.stride(0),
+                                     _dt(x), _ptr(ws), nbytes, _stream()), "mi_w4a16_gemm_silu_mul")
+    return out

@@ -71,7 +71,35 @@ class AWQConfig(QuantizationConfig):
         return None
 
 
-class AWQLinearMethod(LinearMethodBase):
+class W4FusedDecodeMixin:
+    """Decode-batch fused forms of an int4 linear whose weights are in the native layout (after
+    process_weights_after_loading): the GEMM's split-K slabs are consumed by ONE kernel that also runs the decoder
+    layer's next op(s) -- what harness.LlamaStack.forward_decode_fused16 calls.  16-bit activations in and out;
+    bit-identical to apply() followed by the unfused kernels."""
+
+    @staticmethod
+    def fused_decode16_ok(layer: torch.nn.Module, M: int) -> bool:
+        if not getattr(layer, "mi_w4_native", False) or getattr(layer, "mi_perm", None) is not None:
+            return False
+        if getattr(layer, "bias", None) is not None:
+            return False
+        K = layer.qweight.numel() * 8 // layer.mi_out_features
+        return ops.w4a16_fused_ok(M, layer.mi_out_features, K, layer.mi_group_size)
+
+    def apply_add_rmsnorm16(self, layer, x, residual, norm_weight, eps):
+        return ops.w4a16_gemm_add_rmsnorm(x, layer.qweight, layer.qzeros, layer.mi_out_features, layer.mi_group_size,
+                                          residual, norm_weight, eps)
+
+    def apply_rope_kvwrite16(self, layer, x, positions, cos_sin_cache, k_cache, v_cache, loc, num_q_heads, num_kv_heads,
+                             head_dim):
+        return ops.w4a16_gemm_rope_kvwrite(x, layer.qweight, layer.qzeros, layer.mi_group_size, positions, cos_sin_cache,
+                                           k_cache, v_cache, loc, num_q_heads, num_kv_heads, head_dim)
+
+    def apply_silu_mul16(self, layer, x):
+        return ops.w4a16_gemm_silu_mul(x, layer.qweight, layer.qzeros, layer.mi_out_features, layer.mi_group_size)
+
+
+class AWQLinearMethod(W4FusedDecodeMixin, LinearMethodBase):
     def __init__(self, quant_config: AWQConfig):
         self.quant_config = quant_config
 

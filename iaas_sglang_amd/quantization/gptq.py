@@ -17,6 +17,7 @@ from .. import ops
 from .._compat import (GroupQuantScaleParameter, LinearBase, LinearMethodBase, PackedvLLMParameter,
                        QuantizationConfig)
 from .._lib import MI_W4_GPTQ
+from .awq import W4FusedDecodeMixin
 
 
 class GPTQConfig(QuantizationConfig):
@@ -68,7 +69,7 @@ class GPTQConfig(QuantizationConfig):
         return None
 
 
-class GPTQLinearMethod(LinearMethodBase):
+class GPTQLinearMethod(W4FusedDecodeMixin, LinearMethodBase):
     def __init__(self, quant_config: GPTQConfig):
         self.quant_config = quant_config
 

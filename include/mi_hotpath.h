@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
@@ -457,6 +457,28 @@ int mi_fp8_gemm_silu_mul_fp8(const void* a, const void* b_nk, const float* scale
                              const float* scale_b, void* q_out, const float* q_scale, int64_t M,
                              int64_t I, int64_t K, int64_t lda, int64_t ldb, int dtype,
                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------- decode-shaped int4 (AWQ / GPTQ without act-order) linears fused with their consumer
+ *
+ * M <= 128, K % 128 == 0, N % 64 == 0, group_size % 128 == 0; 16-bit activations in and out.  The GEMM leaves raw fp32
+ * split-K partials in `workspace` (mi_w4a16_fused_workspace_bytes() bytes, 16-byte aligned) and ONE consumer kernel sums
+ * them, rounds to T (what mi_w4a16_gemm returns without a bias) and applies the next op(s) of the decoder layer:
+ * bit-identical to mi_w4a16_gemm followed by the unfused kernels.
+ * replaces: AWQLinearMethod.apply (awq.py:199-203: awq_dequantize + torch.matmul) / vllm gptq_gemm, followed by
+ * RMSNorm.forward_native with residual (layernorm.py:128-146); RotaryEmbedding.forward_native
+ * (rotary_embedding.py:49-166) + set_kv_buffer (memory_pool.py:454-455); SiluAndMul.forward_native (activation.py:56-58). */
+int64_t mi_w4a16_fused_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t group_size);
+int mi_w4a16_gemm_add_rmsnorm(const void* x, const void* qw_native, const void* zs_native, void* residual,
+                              const void* norm_weight, void* out, int64_t M, int64_t N, int64_t K, int64_t group_size,
+                              int64_t ldx, float eps, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int mi_w4a16_gemm_rope_kvwrite(const void* x, const void* qw_native, const void* zs_native, const int64_t* positions,
+                               const float* cos_sin_cache, void* q_out, void* k_cache, void* v_cache, const int64_t* loc,
+                               int64_t M, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t K,
+                               int64_t group_size, int64_t ldx, int64_t ldq, int64_t cache_stride_k, int64_t cache_stride_v,
+                               int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int mi_w4a16_gemm_silu_mul(const void* x, const void* qw_native, const void* zs_native, void* out, int64_t M, int64_t I,
+                           int64_t K, int64_t group_size, int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -243,3 +243,107 @@ def test_fused_entry_points_reject_bad_arguments():
     qx, w, xs, ws = _fp8_operands(8, 256, 192, g)            # K % 128 != 0
     with pytest.raises(MiHotpathError):
         ops.fp8_gemm_add_rmsnorm(qx, w, xs, ws, None, torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-5)
+
+
+# ---------------------------------------------------------------- int4 (AWQ) linears fused with their consumer
+def _awq_weight(N, K, g, dtype, group=128):
+    from iaas_sglang_amd import ops
+    qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, generator=g)
+    qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // group, N // 8), dtype=torch.int32, generator=g)
+    scales = (torch.rand(K // group, N, generator=g) * 0.004 + 0.001).to(dtype)
+    qw, zs, _ = ops.w4_repack(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), group, ops.MI_W4_AWQ)
+    return qw, zs
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (7, 4096, 4096), (33, 1024, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_w4_gemm_add_rmsnorm_bit_identical(M, N, K, dtype):
+    """mi_w4a16_gemm_add_rmsnorm == mi_w4a16_gemm (awq.py:199-203) then mi_rmsnorm with residual (layernorm.py:128-146)."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    qw, zs = _awq_weight(N, K, g, dtype)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    res = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(DEV)
+    assert ops.w4a16_fused_ok(M, N, K, 128)
+    y = ops.w4a16_gemm(x, qw, zs, N, 128)
+    r1 = res.clone()
+    out1 = ops.rmsnorm(y, nw, 1e-5, residual=r1)
+    r2 = res.clone()
+    out2 = ops.w4a16_gemm_add_rmsnorm(x, qw, zs, N, 128, r2, nw, 1e-5)
+    out3 = ops.w4a16_gemm_add_rmsnorm(x, qw, zs, N, 128, None, nw, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out1), _bits(out2)) and torch.equal(_bits(r1), _bits(r2))
+    assert torch.equal(_bits(ops.rmsnorm(y, nw, 1e-5)), _bits(out3))
+
+
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(64, 32, 32, 128, 4096), (5, 32, 8, 128, 4096), (128, 8, 8, 64, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_w4_gemm_rope_kvwrite_bit_identical(M, Hq, Hkv, D, K, dtype):
+    """mi_w4a16_gemm_rope_kvwrite == mi_w4a16_gemm, NeoX RoPE (rotary_embedding.py:49-166), set_kv_buffer."""
+    from iaas_sglang_amd import harness as H, ops
+    g = torch.Generator().manual_seed(M + Hq + K)
+    N = (Hq + 2 * Hkv) * D
+    qw, zs = _awq_weight(N, K, g, dtype)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    slots = 4 * M + 8
+    kc = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    vc = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    loc = (torch.randperm(slots - 1, generator=g)[:M] + 1).to(torch.int64).to(DEV)
+    pos = torch.randint(0, 4000, (M,), generator=g).to(torch.int64).to(DEV)
+    cs = H.rope_cache(D, 4096, 10000.0, DEV)
+    qkv = ops.w4a16_gemm(x, qw, zs, N, 128)
+    q1, k1, v1 = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    ops.rope_neox_(q1, k1, pos, cs, D)
+    kc1, vc1 = kc.clone(), vc.clone()
+    ops.kv_write(kc1, vc1, loc, k1.reshape(M, Hkv, D).contiguous(), v1.reshape(M, Hkv, D).contiguous())
+    kc2, vc2 = kc.clone(), vc.clone()
+    q2 = ops.w4a16_gemm_rope_kvwrite(x, qw, zs, 128, pos, cs, kc2, vc2, loc, Hq, Hkv, D)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(q1.contiguous()), _bits(q2))
+    assert torch.equal(_bits(kc1), _bits(kc2)) and torch.equal(_bits(vc1), _bits(vc2))
+
+
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 4096), (128, 11008, 4096), (3, 512, 256)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_w4_gemm_silu_mul_bit_identical(M, I, K, dtype):
+    """mi_w4a16_gemm_silu_mul == mi_w4a16_gemm then mi_silu_and_mul (activation.py:56-58)."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(M + I + K)
+    qw, zs = _awq_weight(2 * I, K, g, dtype)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    want = ops.silu_and_mul(ops.w4a16_gemm(x, qw, zs, 2 * I, 128))
+    got = ops.w4a16_gemm_silu_mul(x, qw, zs, 2 * I, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(want), _bits(got))
+
+
+def test_llama2_awq_layer_stack_fused_equals_unfused():
+    """Two Llama-2-7B-shaped AWQ layers (configuration C4 at its batch 64, KV 512): logits and KV-pool contents of the
+    fused decode step (7 launches per layer) are bit-identical to the unfused plugin-surface sequence (17)."""
+    import dataclasses
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    from iaas_sglang_amd.quantization import AWQConfig
+    shape = dataclasses.replace(H.LLAMA2_7B, layers=2, vocab=4096)
+    dtype, batch, seq = torch.float16, 64, 512
+    awq = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    runner = H.make_runner(shape, max_reqs=batch, ctx=seq + 8, pool_tokens=batch * seq, dtype=dtype, device=DEV, fill_kv=True)
+    backend = MiAttnBackend(runner)
+    stack = H.LlamaStack(shape, lambda: awq.get_quant_method(None, ""), dtype, DEV)
+    fb = H.make_decode_batch(runner, backend, batch, seq, DEV, seed=3)
+    hidden = torch.randn(batch, shape.hidden, generator=torch.Generator().manual_seed(1)).to(dtype).to(DEV)
+    backend.init_forward_metadata(fb)
+    pool = runner.token_to_kv_pool
+    snap = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    assert stack._fused_decode16_ok(hidden, fb)
+    l_unfused = _decode_logits(stack, runner, backend, fb, hidden, fused=False)
+    kv_unfused = [b.clone() for b in pool.k_buffer + pool.v_buffer]
+    for b, s0 in zip(pool.k_buffer + pool.v_buffer, snap):
+        b.copy_(s0)
+    l_fused = _decode_logits(stack, runner, backend, fb, hidden, fused=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(l_fused.float()).all())
+    assert torch.equal(_bits(l_unfused), _bits(l_fused))
+    for b, ref in zip(pool.k_buffer + pool.v_buffer, kv_unfused):
+        assert torch.equal(_bits(b), _bits(ref))

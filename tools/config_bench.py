@@ -30,6 +30,8 @@ tot = int(lens.sum())
 runner = H.make_runner(shape, max_reqs=B, ctx=2 * S + 8, pool_tokens=tot + 8, dtype=dtype, device=dev, fill_kv=True)
 backend = MiAttnBackend(runner)
 stack = H.LlamaStack(shape, make, dtype, dev)
+if os.environ.get("MI_NO_FUSE") == "1":     # A/B: the unfused plugin-surface sequence
+    H.LlamaStack.fuse_decode_layer = False
 fb = H.make_decode_batch(runner, backend, B, 0, dev, seed=0, ragged=lens)
 ids = torch.randint(0, shape.vocab, (B,), device=dev)
 out_ids = torch.empty_like(ids)
