@@ -38,15 +38,20 @@ for N, K in [(28672, 4096), (6144, 4096), (4096, 4096), (4096, 14336)]:
     nwg = int(used[:, 0].sum())
     print(f"N={N} K={K}: workgroups {int(used[:, 0].sum())}, phases/wg {float(ph.mean()) / (reps * len(ws)):.1f}")
     nwg = int(used[:, 0].sum())
-    tot = t[:nwg, :4, 4].sum() / max(t[:nwg, :4, 3].sum(), 1) * float(ph.mean()) / (reps * len(ws)) if nwg else 0
-    rt = t[:nwg, :4, 5].sum() / max(t[:nwg, :4, 3].sum(), 1) * float(ph.mean()) / (reps * len(ws)) if nwg else 0
-    print(f"   consumers: entry -> end of main loop {float(tot):9.0f} cycles = {float(rt) / 100:7.2f} us  (clock {float(tot) / max(float(rt), 1e-9) * 100:6.0f} MHz)")
-    a0, a1 = t[:nwg, :4, 6], t[:nwg, :4, 7]
-    base = float(a0.min())
-    print(f"   last launch, 100 MHz ticks from the first entry: entries {float(a0.mean() - base) / 100:6.2f} us mean, {float(a0.max() - base) / 100:6.2f} max;"
-          f" end of main loop {float(a1.mean() - base) / 100:6.2f} mean, {float(a1.min() - base) / 100:6.2f} min, {float(a1.max() - base) / 100:6.2f} max")
-    # role kernel (MI_GEMM_XW=1): waves 0-3 consumers (compute | - | barrier), waves 4-7 loaders (issue | vmcnt wait | barrier)
-    for name, i in (("compute/issue", 0), ("vmcnt wait", 1), ("barrier", 2), ("  dma issue", 4), ("  frag reads", 5), ("  mfma", 6)):
+    # role kernel (MI_GEMM_XW != 0): waves 0-3 consumers (compute | - | barrier), waves 4-7 loaders (issue | vmcnt | barrier)
+    roles = os.environ.get("MI_GEMM_XW", "1") != "0"
+    if roles and nwg:
+        norm = float(ph.mean()) / (reps * len(ws)) / max(float(t[:nwg, :4, 3].sum()), 1.0)
+        tot, rt = float(t[:nwg, :4, 4].sum()) * norm, float(t[:nwg, :4, 5].sum()) * norm
+        print(f"   consumers: entry -> end of main loop {tot:9.0f} cycles = {rt / 100:7.2f} us  (clock {tot / max(rt, 1e-9) * 100:6.0f} MHz)")
+        a0, a1 = t[:nwg, :4, 6], t[:nwg, :4, 7]
+        base = float(a0.min())
+        print(f"   last launch, 100 MHz ticks from the first entry: entries {float(a0.mean() - base) / 100:6.2f} us mean, "
+              f"{float(a0.max() - base) / 100:6.2f} max; end of main loop {float(a1.mean() - base) / 100:6.2f} mean, "
+              f"{float(a1.min() - base) / 100:6.2f} min, {float(a1.max() - base) / 100:6.2f} max")
+    rows = (("compute/issue", 0), ("vmcnt wait", 1), ("barrier", 2)) if roles else \
+           (("compute", 0), ("vmcnt wait", 1), ("barrier", 2), ("  dma issue", 4), ("  frag reads", 5), ("  mfma issue", 6))
+    for name, i in rows:
         per = (t[:, :, i][used] / ph)
         pw = (t[:nwg, :, i] / t[:nwg, :, 3].clamp(min=1)).mean(0)
         print(f"   {name:13s} mean {float(per.mean()):7.0f} cyc/phase   per wave: " + " ".join(f"{float(v):6.0f}" for v in pw))
