@@ -45,6 +45,7 @@ SIGNATURES = {
                                     _i64, _i64, _f, _f, _i64, _i64, _p, _i64, _p, _int, _p]),
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
+    "mi_extend_attn_paged": (_int, [_p] * 11 + [_i64] * 12 + [_f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_splitkv": (_int, [_p] * 6 + [_int, _f, _f] + [_p] * 5 + [_int] + [_i64] * 11 + [_f, _f, _int, _i64, _p, _i64, _i64,

@@ -347,6 +347,13 @@ class MiAttnBackend(AttentionBackend):
             tokens = int(sum(ext_cpu)) if ext_cpu is not None else 0
             self.forward_metadata = ForwardMetadata(kv_indptr, kv_indices, qo_indptr, max_ext, splits,
                                                     self._workspace(tokens, splits))
+            if self.page_size > 1 and prefix_sum > 0:
+                # paged pool: one index per page of the cached prefix for the long-extend kernel
+                pages = torch.empty(-(-prefix_sum // self.page_size) + bs, dtype=torch.int32, device=self.device)
+                pi, px = ops.kv_page_tables(self.req_to_token, forward_batch.req_pool_indices,
+                                            forward_batch.extend_prefix_lens, self.page_size, self.page_indptr, pages)
+                self.forward_metadata.page_indptr, self.forward_metadata.page_indices = pi, px
+                self.forward_metadata.page_size = self.page_size
 
     def _draft_extend_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, spec_info, ext_cpu=None,
                                seq_lens_cpu=None, kv_indices=None, splits=None, workspace=None,
@@ -675,6 +682,11 @@ class MiAttnBackend(AttentionBackend):
             ks, vs = self._kv_scales(layer)
             ops.extend_attention_fp8kv(q3, k3, v3, o3, k_buf, v_buf, ks, vs, md.qo_indptr, md.kv_indptr, md.kv_indices,
                                        md.max_extend_len, layer.scaling, cap, causal, window if window > 0 else -1)
+            return o
+        if md.page_indptr is not None:
+            ops.extend_attention_paged(q3, k3, v3, o3, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices,
+                                       md.page_indptr, md.page_indices, md.page_size, md.max_extend_len, layer.scaling,
+                                       cap, causal, window if window > 0 else -1)
             return o
         ops.extend_attention(q3, k3, v3, o3, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices, md.max_extend_len,
                              layer.scaling, cap, causal, window if window > 0 else -1)

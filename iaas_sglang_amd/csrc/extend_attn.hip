@@ -48,6 +48,12 @@ struct ExtendParams {
   int32_t num_splits;
   float* ws_o;
   float* ws_ml;
+  // page-granular prefix (extend_attn32_kernel only; page_shift = log2(page size), 0 = token-granular): prefix key j of
+  // request i is slot page_indices[page_indptr[i] + (j >> page_shift)] * page + (j & (page - 1)) -- one index per page of
+  // a page-aligned pool (PagedTokenToKVPoolAllocator, allocator.py:407-543) instead of one kv_indices entry per key
+  const int32_t* page_indptr;
+  const int32_t* page_indices;
+  int32_t page_shift;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -437,6 +443,8 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   const int32_t n_keys = prefix + (causal ? blk_last : ext_len);
   const int32_t n_tiles = (n_keys + KT - 1) / KT;
   const int32_t wave_keys = causal ? prefix + min(ext_len, tok0 + 32) : n_keys;   // keys this wave can see (exclusive)
+  const int pshift = p.page_shift;
+  const int32_t pg_base = pshift ? p.page_indptr[req] : 0;
 
   // ---- staging: thread -> 16-byte chunk (tid & 15) of key rows (tid >> 4) and 32 + (tid >> 4) of the tile
   const int srow = tid >> 4, sch = tid & 15;
@@ -451,7 +459,8 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   {                                                                                                                 \
     const int32_t kp_ = min((tile_) * KT + RP * (ps_) + srow, n_keys - 1);                                          \
     const bool in_pool_ = kp_ < prefix;                                                                             \
-    const int64_t slot_ = in_pool_ ? (int64_t)p.kv_indices[kv_base + kp_] : 0;                                      \
+    const int64_t slot_ = !in_pool_ ? 0 : pshift == 0 ? (int64_t)p.kv_indices[kv_base + kp_]                        \
+        : ((int64_t)p.page_indices[pg_base + (kp_ >> pshift)] << pshift) + (kp_ & ((1 << pshift) - 1));             \
     const int64_t t_ = q_start + max(kp_ - prefix, 0);                                                              \
     const int64_t ko_ = (in_pool_ ? slot_ * p.stride_k_slot : t_ * p.stride_kx_tok) + hd_off;                       \
     const int64_t vo_ = same_strides ? ko_ : (in_pool_ ? slot_ * p.stride_v_slot : t_ * p.stride_vx_tok) + hd_off;  \
@@ -749,7 +758,8 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
                             int64_t sliding_window, int dtype, void* stream, bool kv8, float k_scale, float v_scale,
                             const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
                             int skip_prefix_mask = 1, void* workspace = nullptr, int64_t total_tokens = 0,
-                            int64_t num_splits = 1) {
+                            int64_t num_splits = 1, const int32_t* page_indptr = nullptr,
+                            const int32_t* page_indices = nullptr, int64_t page_size = 1) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
   MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
@@ -778,6 +788,11 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   MI_CHECK_ARG(!custom_mask || mask_indptr);
   p.custom_mask = custom_mask; p.mask_indptr = mask_indptr; p.skip_prefix_mask = skip_prefix_mask;
   p.num_splits = (int32_t)num_splits;
+  p.page_indptr = page_indptr; p.page_indices = page_indices; p.page_shift = 0;
+  if (page_indptr && page_indices && page_size > 1) {
+    MI_CHECK_ARG((page_size & (page_size - 1)) == 0 && page_size <= (1 << 20));
+    while ((1ll << p.page_shift) < page_size) ++p.page_shift;
+  }
   p.ws_o = (float*)workspace;
   p.ws_ml = p.ws_o ? p.ws_o + total_tokens * num_q_heads * num_splits * head_dim : nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -828,6 +843,24 @@ extern "C" int mi_extend_attn(const void* q_ext, const void* k_ext, const void* 
                           num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
                           stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype, stream, false,
                           1.f, 1.f);
+}
+
+// mi_extend_attn on a page-aligned pool: the 32x32x16 kernel (head_dim 128, extends >= 64 tokens, no mask / window /
+// cap) takes ONE index per page of the cached prefix; every other case runs the token-granular kernels on kv_indices.
+extern "C" int mi_extend_attn_paged(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                                    const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                                    const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* page_indptr,
+                                    const int32_t* page_indices, int64_t page_size, int64_t batch,
+                                    int64_t max_extend_len, int64_t num_q_heads, int64_t num_kv_heads,
+                                    int64_t head_dim, int64_t stride_q_tok, int64_t stride_o_tok,
+                                    int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                                    int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                                    int64_t sliding_window, int dtype, void* stream) {
+  MI_CHECK_ARG(kv_indices && page_indptr && page_indices && page_size >= 1 && (page_size & (page_size - 1)) == 0);
+  return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch, max_extend_len,
+                          num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
+                          stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype, stream, false,
+                          1.f, 1.f, nullptr, nullptr, 1, nullptr, 0, 1, page_indptr, page_indices, page_size);
 }
 
 extern "C" int mi_extend_attn_fp8kv(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,

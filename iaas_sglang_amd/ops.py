@@ -281,6 +281,29 @@ def extend_attention(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, 
     return o
 
 
+def extend_attention_paged(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
+                           k_buf: torch.Tensor, v_buf: torch.Tensor, qo_indptr: torch.Tensor,
+                           kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, page_indptr: torch.Tensor,
+                           page_indices: torch.Tensor, page_size: int, max_extend_len: int, sm_scale: float,
+                           logit_cap: float = 0.0, causal: bool = True, sliding_window: int = -1) -> torch.Tensor:
+    """extend_attention on a page-aligned pool: one page id per page of the cached prefix (kv_page_tables on the
+    prefix lengths) for the long-extend kernel, kv_indices for every shape that kernel does not take; same bits."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, o, k_ext, v_ext, k_buf, v_buf):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    for t in (qo_indptr, kv_indptr_t, kv_indices_t, page_indptr, page_indices):
+        assert t.dtype == torch.int32
+    check(lib.mi_extend_attn_paged(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o), _ptr(k_buf), _ptr(v_buf), _ptr(qo_indptr),
+                                   _ptr(kv_indptr_t), _ptr(kv_indices_t), _ptr(page_indptr), _ptr(page_indices),
+                                   int(page_size), B, int(max_extend_len), Hq, Hkv, D, q.stride(0), o.stride(0),
+                                   k_ext.stride(0), v_ext.stride(0), k_buf.stride(0), v_buf.stride(0), float(sm_scale),
+                                   float(logit_cap), int(causal), int(sliding_window), _dt(q), _stream()),
+          "mi_extend_attn_paged")
+    return o
+
+
 def extend_attention_fp8kv(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
                            k_buf8: torch.Tensor, v_buf8: torch.Tensor, k_scale: float, v_scale: float,
                            qo_indptr: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,

@@ -207,6 +207,20 @@ int mi_extend_attn(const void* q_ext, const void* k_ext, const void* v_ext, void
                    int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                    int64_t sliding_window, int dtype, void* stream);
 
+/* mi_extend_attn over a page-aligned pool (page_size a power of two; PagedTokenToKVPoolAllocator, allocator.py:407-543):
+ * page_indices[page_indptr[i] .. page_indptr[i+1]) = the page ids of request i's cached prefix (mi_kv_page_indptr /
+ * mi_kv_page_indices on the prefix lengths); prefix key j is slot page * page_size + j % page_size.  The long-extend
+ * kernel reads one index per page; shapes it does not take run on kv_indices (must be given too).  Same bits as
+ * mi_extend_attn.  replaces: the prefix loop of extend_attention_fwd (extend_attention.py:118-196) on a paged pool. */
+int mi_extend_attn_paged(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext,
+                         const void* k_buf, const void* v_buf, const int32_t* qo_indptr,
+                         const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* page_indptr,
+                         const int32_t* page_indices, int64_t page_size, int64_t batch, int64_t max_extend_len,
+                         int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                         int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                         int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
+                         int64_t sliding_window, int dtype, void* stream);
+
 /* mi_extend_attn whose cached PREFIX lives in an fp8 (e4m3fn) pool: k_buf8/v_buf8 hold bytes, stride_*_slot in
  * BYTES, head_dim 128; prefix keys are k8 * k_scale, prefix values v8 * v_scale (converted while being staged);
  * the new tokens k_ext/v_ext stay T-typed.  replaces: extend_attention_fwd over an fp8 MHATokenToKVPool. */

@@ -879,3 +879,114 @@ def test_extend_output_row_pitch_fallback():
     torch.cuda.synchronize()
     torch.testing.assert_close(o_pitch.float(), o_ref.float(), atol=4e-3, rtol=2 ** -6)
     assert float(big[:, Hq * D:].abs().max()) == 0.0                   # nothing written past the rows
+
+
+# ---------------------------------------------------------------- page-granular prefix in extend (SURVEY 8f-3 remainder)
+def _paged_prefix_case(g, pre, ext, page_size, Hq=32, Hkv=8, D=128, dtype=torch.bfloat16):
+    """Requests own whole pages in random order (PagedTokenToKVPoolAllocator layout); returns everything both forms need."""
+    from iaas_sglang_amd import ops
+    lens = [p + e for p, e in zip(pre, ext)]
+    need = [-(-L // page_size) for L in lens]
+    order = torch.randperm(sum(need), generator=g) + 1
+    slots = (sum(need) + 1) * page_size
+    B = len(lens)
+    r2t = torch.zeros(B, max(lens) + 1, dtype=torch.int32)
+    off = 0
+    for i, L in enumerate(lens):
+        pg = order[off: off + need[i]]
+        off += need[i]
+        r2t[i, :L] = (pg[:, None] * page_size + torch.arange(page_size)[None, :]).reshape(-1)[:L].to(torch.int32)
+    kc = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    vc = torch.randn(slots, Hkv, D, generator=g).to(dtype).to(DEV)
+    E = sum(ext)
+    q = torch.randn(E, Hq, D, generator=g).to(dtype).to(DEV)
+    kn = torch.randn(E, Hkv, D, generator=g).to(dtype).to(DEV)
+    vn = torch.randn(E, Hkv, D, generator=g).to(dtype).to(DEV)
+    rpi = torch.arange(B, dtype=torch.int64, device=DEV)
+    pre_d = torch.tensor(pre, dtype=torch.int32, device=DEV)
+    ext_d = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    kvp, qop = ops.kv_indptr(pre_d).clone(), ops.kv_indptr(ext_d).clone()
+    idx = torch.empty(max(1, sum(pre)), dtype=torch.int32, device=DEV)
+    ops.kv_indices(r2t.to(DEV), rpi, pre_d, kvp, idx)
+    pi, px = ops.kv_page_tables(r2t.to(DEV), rpi, pre_d, page_size)
+    return q, kn, vn, kc, vc, qop, kvp, idx, pi.clone(), px
+
+
+@pytest.mark.parametrize("page_size", [16, 64])
+@pytest.mark.parametrize("pre,ext", [([1024] * 4, [256] * 4), ([0, 17, 2048, 63, 640], [2048, 64, 100, 700, 129])])
+def test_extend_page_granular_prefix_is_bit_identical_to_token_granular(page_size, pre, ext):
+    """mi_extend_attn_paged (one page id per page of the cached prefix in extend_attn32_kernel, kv_indices for the rows
+    the 16x16 kernel takes) against mi_extend_attn on the same page-aligned pool: the same bits."""
+    from iaas_sglang_amd import ops
+    g = torch.Generator().manual_seed(page_size + len(pre))
+    q, kn, vn, kc, vc, qop, kvp, idx, pi, px = _paged_prefix_case(g, pre, ext, page_size)
+    D = q.shape[2]
+    o1, o2 = torch.empty_like(q), torch.empty_like(q)
+    ops.extend_attention(q, kn, vn, o1, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1)
+    ops.extend_attention_paged(q, kn, vn, o2, kc, vc, qop, kvp, idx, pi, px, page_size, max(ext), D ** -0.5, 0.0, True, -1)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    # a wrong page table must change the result (the kernel really reads it) when some request has a long extend + prefix
+    if any(p > 0 and e >= 64 for p, e in zip(pre, ext)):
+        o3 = torch.empty_like(q)
+        used = int(pi[-1])                                  # only VALID page ids, in another order (stays in bounds)
+        wrong = px.clone()
+        wrong[:used] = torch.roll(px[:used], 1)
+        ops.extend_attention_paged(q, kn, vn, o3, kc, vc, qop, kvp, idx, pi, wrong, page_size,
+                                   max(ext), D ** -0.5, 0.0, True, -1)
+        torch.cuda.synchronize()
+        assert not torch.equal(o1.view(torch.int16), o3.view(torch.int16))
+
+
+@pytest.mark.parametrize("page_size", [16, 64])
+def test_backend_extend_on_a_paged_pool_uses_page_tables(page_size):
+    """MiAttnBackend on a runner with page_size >= 16: EXTEND metadata carries the prefix page tables and forward_extend
+    takes mi_extend_attn_paged; result = the fp32 oracle."""
+    from iaas_sglang_amd import harness as H
+    from iaas_sglang_amd.attention_backend import MiAttnBackend
+    Hq, Hkv, D, dtype = 32, 8, 128, torch.bfloat16
+    pre, ext = [512, 0, 1000], [300, 128, 65]
+    lens = [p + e for p, e in zip(pre, ext)]
+    pool_tokens = (sum(-(-L // page_size) for L in lens) + 2) * page_size
+    runner = H.make_runner(H.LLAMA3_8B, max_reqs=4, ctx=2048, pool_tokens=pool_tokens, dtype=dtype, device=DEV)
+    runner.token_to_kv_pool = H.make_kv_pool(pool_tokens, 1, Hkv, D, dtype, DEV, fill_random=True)
+    runner.page_size = page_size
+    backend = MiAttnBackend(runner)
+    assert backend.page_size == page_size
+    g = torch.Generator().manual_seed(3)
+    # page-aligned layout: request i owns whole pages in random order
+    need = [-(-L // page_size) for L in lens]
+    order = torch.randperm(sum(need), generator=g) + 1
+    r2t = runner.req_to_token_pool.req_to_token
+    off, loc = 0, []
+    for i, L in enumerate(lens):
+        pg = order[off: off + need[i]]
+        off += need[i]
+        sl = (pg[:, None] * page_size + torch.arange(page_size)[None, :]).reshape(-1)[:L]
+        r2t[i, :L] = sl.to(torch.int32).to(DEV)
+        loc.append(sl[pre[i]:])
+    loc = torch.cat(loc).to(torch.int64)
+    from types import SimpleNamespace
+    fb = SimpleNamespace(forward_mode=H.ForwardMode.EXTEND, batch_size=3,
+                         req_pool_indices=torch.arange(3, dtype=torch.int64, device=DEV),
+                         seq_lens=torch.tensor(lens, dtype=torch.int64, device=DEV), seq_lens_sum=sum(lens),
+                         extend_prefix_lens=torch.tensor(pre, dtype=torch.int64, device=DEV),
+                         extend_seq_lens=torch.tensor(ext, dtype=torch.int64, device=DEV),
+                         extend_prefix_lens_cpu=pre, extend_seq_lens_cpu=ext, out_cache_loc=loc.to(DEV),
+                         req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                         attn_backend=backend, spec_info=None, positions=None)
+    layer = H.AttnLayer(Hq, D, D ** -0.5, Hkv, 0)
+    E = sum(ext)
+    q = torch.randn(E, Hq * D, generator=g).to(dtype)
+    k = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(E, Hkv, D, generator=g).to(dtype)
+    pool = runner.token_to_kv_pool
+    kc, vc = pool.k_buffer[0].cpu().clone(), pool.v_buffer[0].cpu().clone()
+    backend.init_forward_metadata(fb)
+    assert backend.forward_metadata.page_indptr is not None and backend.forward_metadata.page_size == page_size
+    o = backend.forward(q.to(DEV), k.to(DEV), v.to(DEV), layer, fb)
+    torch.cuda.synchronize()
+    oa.set_kv_buffer(kc, vc, loc, k, v)
+    ref = oa.extend_fp32(q.view(-1, Hq, D), kc, vc, r2t.cpu(), torch.arange(3), torch.tensor(lens), torch.tensor(pre),
+                         torch.tensor(ext), scaling=D ** -0.5, causal=True)
+    torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=4e-3, rtol=2 ** -6)
