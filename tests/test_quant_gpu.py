@@ -78,6 +78,9 @@ def test_fp8_gemm_golden(golden_quant, name):
                                    # C5 per rank (Llama-3-70B, TP=8, batch 256): qkv, o, gate_up, down
                                    (256, 1280, 8192), (256, 8192, 1024), (256, 7168, 8192), (256, 8192, 3584),
                                    (136, 4096, 4096), (500, 4096, 2048),           # chunks of rows: 136, 256 + 244
+                                   # role kernel (fp8_gemm_xw_kernel) with a ragged last column block (per-lane
+                                   # epilogue, clamped weight rows), a single k-phase, few rows
+                                   (100, 1088, 384), (37, 2064, 256), (128, 1040, 128), (7, 4160, 512),
                                    (1100, 4096, 14336), (2000, 1024, 4096),        # tile kernel with split-K slabs (S = 4, 2..4)
                                    # more tiles than CUs: the persistent tile loop (next tile's first stage requested in
                                    # the last k-step, LDS-staged line stores) with ragged last row / column blocks
