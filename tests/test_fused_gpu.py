@@ -25,7 +25,8 @@ def _bits(t):
     return t.view(torch.uint8) if t.dtype == FP8 else t.view(torch.int16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 4096, 4096), (128, 4096, 14336), (37, 4096, 4096), (1, 256, 512), (16, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 4096, 4096), (128, 4096, 14336), (37, 4096, 4096), (1, 256, 512), (16, 1024, 256),
+                                   (128, 4096, 2048), (128, 4096, 512), (128, 4096, 1792)])     # o / down per rank at TP = 2, 8
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_residual", [True, False])
 def test_gemm_add_rmsnorm_fp8_bit_identical(M, N, K, dtype, with_residual):
