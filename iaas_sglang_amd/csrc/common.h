@@ -155,14 +155,6 @@ __device__ __forceinline__ void glds16_s(uint32_t lane_off, const uint8_t* sbase
                : "v"(lane_off), "s"(sbase), "s"(lds_dst)
                : "memory");
 }
-// the same with the non-temporal cache policy: for bytes ONE CU reads once (decode weight streams)
-__device__ __forceinline__ void glds16_s_nt(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(lane_off), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
 // the 4-byte form: 256 B per wave instruction, lane L -> LDS byte lds_dst + 4 L
 __device__ __forceinline__ void glds4_s(uint32_t lane_off, const uint8_t* sbase, uint32_t lds_dst) {
   uint32_t keep;

@@ -625,9 +625,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     xlds[i] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
   }
   const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_base + XBYTES + wave * 2 * 1024);
-  const int var = p.var;
-  const bool late = (var & 2) && __builtin_amdgcn_readfirstlane(wave) >= 4;   // stagger: waves 4-7 compute, then issue
-  if ((var & 8) && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+  const int var = p.var;      // diagnostic builds: bit 16 = phase stamps, bit 32 = finer stamps
+  (void)var;
 
   auto issue = [&](int64_t ph) __attribute__((always_inline)) {
     const uint32_t st = (uint32_t)((ph - ph0) % R) * STAGE;
@@ -635,13 +634,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
     const uint8_t* wa = p.b + ph * PB;
 #pragma unroll
     for (int i = 0; i < XD; ++i) glds16_s(xoff[i], xa, xlds[i] + st);
-    if (var & 1) {
-      glds16_s_nt(woff[0], wa, wlds + st);
-      glds16_s_nt(woff[1], wa, wlds + st + 1024);
-    } else {
-      glds16_s(woff[0], wa, wlds + st);
-      glds16_s(woff[1], wa, wlds + st + 1024);
-    }
+    glds16_s(woff[0], wa, wlds + st);
+    glds16_s(woff[1], wa, wlds + st + 1024);
   };
   // fragment (row, 16-byte slot) of a tile whose rows are 128 B: line pair = row >> 1, physical position
   // ((row & 1) * 8 + slot) ^ (line & 15)
@@ -711,37 +705,19 @@ __global__ __launch_bounds__(512) void fp8_gemm_xd_kernel(const GemmParams p, fl
       } else
 #endif
       wait_phase(ph);                                    // phase ph landed everywhere; everyone is done with ph-1
-      if (!late && ph + D < ph1) issue(ph + D);          // into the stage phase ph-1 used
+      if (ph + D < ph1) issue(ph + D);                   // into the stage phase ph-1 used
       if (tile_ok) {
         const char* xb = smem + ((ph - ph0) % R) * STAGE;
         const char* wb = xb + XBYTES;
         const uint4 w0 = frag(wb, wave * 16 + r16, q), w1 = frag(wb, wave * 16 + r16, 4 + q);
         const i32x8 wf = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
-        if (var & 4) {
-          uint4 x0[MT], x1[MT];
 #pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            x0[t] = frag(xb, t * 16 + r16, q);
-            x1[t] = frag(xb, t * 16 + r16, 4 + q);
-          }
-#pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            const i32x8 xf = {(int)x0[t].x, (int)x0[t].y, (int)x0[t].z, (int)x0[t].w,
-                              (int)x1[t].x, (int)x1[t].y, (int)x1[t].z, (int)x1[t].w};
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * MT, 0);   // every fragment read of the phase first
-          __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);           // then the MFMAs back to back
-        } else {
-#pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            const uint4 x0 = frag(xb, t * 16 + r16, q), x1 = frag(xb, t * 16 + r16, 4 + q);
-            const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-          }
+        for (int t = 0; t < MT; ++t) {
+          const uint4 x0 = frag(xb, t * 16 + r16, q), x1 = frag(xb, t * 16 + r16, 4 + q);
+          const i32x8 xf = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         }
       }
-      if (late && ph + D < ph1) issue(ph + D);
     }
 #ifdef MI_TUNING
     if (stamp && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
@@ -1248,12 +1224,12 @@ static size_t xs_split_lds(int mt) { return 2 * (size_t)mt * 16 * 256 + 3 * (siz
 template <typename OutT, int MT>
 static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStream_t st, bool partial = false, int width = 128) {
   const int nw = xs_waves(p.N);
-  static const int nst4 = mi_tune("MI_GEMM_XS_STAGES", 3);
+  [[maybe_unused]] static const int nst4 = mi_tune("MI_GEMM_XS_STAGES", 3);
   const size_t stage = (size_t)(MT * 16 + nw * 16) * 256;
   dim3 grid((unsigned)cdiv64(p.N, width == 64 ? 64 : 16 * nw), (unsigned)S);
   const int fs = partial ? 1 : 0;
-  static const int split = mi_tune("MI_GEMM_XS_SPLIT", 1);
-  static const int deep = mi_tune("MI_GEMM_XD", 1);
+  [[maybe_unused]] static const int split = mi_tune("MI_GEMM_XS_SPLIT", 1);
+  [[maybe_unused]] static const int deep = mi_tune("MI_GEMM_XD", 1);
   static const int roles = mi_tune("MI_GEMM_XW", 1);    // 0: fp8_gemm_xd_kernel; bit 1 set: per-lane epilogue
   if constexpr (MT == 16) {
     // 129..256 rows in one pass over the weights: 48-KiB stages (x 32 KiB + weights 16 KiB), ring of 3
@@ -1267,12 +1243,14 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
     if (width == 64) fp8_gemm_xw_kernel<OutT, MT, 0, 4, 1><<<grid, 512, xw_lds(MT, 4, 64), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
     else fp8_gemm_xw_kernel<OutT, MT, 0, 4><<<grid, 512, xw_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr}, staged);
   }
+#ifdef MI_TUNING   // the kernels the role kernel replaced, selectable in tuning builds only (MI_GEMM_XW=0 ...)
   else if (nw == 8 && deep == 5) fp8_gemm_xd_kernel<OutT, MT, 0, 5><<<grid, 512, xd_lds(MT, 5), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && deep) fp8_gemm_xd_kernel<OutT, MT, 0, 4><<<grid, 512, xd_lds(MT, 4), st>>>(p, slab, S, 2 * ppw, fs, SiluEpi{nullptr, nullptr});
   else if (nw == 8 && split) fp8_gemm_xs_kernel<OutT, MT, 8, 5><<<grid, 512, xs_split_lds(MT), st>>>(p, slab, S, ppw, fs);
   else if (nw == 8) fp8_gemm_xs_kernel<OutT, MT, 8, 2><<<grid, 512, 2 * stage, st>>>(p, slab, S, ppw, fs);
-  else if (nst4 == 3) fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw, fs);
-  else fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw, fs);
+  else if (nst4 != 3) fp8_gemm_xs_kernel<OutT, MT, 4, 2><<<grid, 256, 2 * stage, st>>>(p, slab, S, ppw, fs);
+#endif
+  else fp8_gemm_xs_kernel<OutT, MT, 4, 3><<<grid, 256, 3 * stage, st>>>(p, slab, S, ppw, fs);   // N < 1024: 4-wave blocks
   if (S > 1 && !partial) {
     const int64_t total = p.M * cdiv64(p.N, 4);
     fp8_gemm_reduce_kernel<OutT><<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(p, slab, S);
@@ -1293,7 +1271,7 @@ static void launch_xs(const GemmParams& p, float* slab, int S, int ppw, hipStrea
 static double tile_time(int64_t M, int64_t N, int64_t K, int* S_out);
 // rows one pass of the decode kernels takes: 256 with the 8-wave deep-ring kernel (MT = 16), else 128
 MI_INTERNAL int64_t mi_fp8_gemm_partial_max_rows(int64_t N) {
-  static const int deep = mi_tune("MI_GEMM_XD", 1), wide = mi_tune("MI_GEMM_XD16", 1);
+  [[maybe_unused]] static const int deep = mi_tune("MI_GEMM_XD", 1), wide = mi_tune("MI_GEMM_XD16", 1);
   return (xs_waves(N) == 8 && deep && wide) ? 256 : 128;
 }
 static bool mid_m_chunked(int64_t M, int64_t N, int64_t K) {
@@ -1931,14 +1909,20 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   const SiluEpi epi{(uint8_t*)q_out, q_scale};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(I / 64), 1);
-  static const int deep = mi_tune("MI_GEMM_XD", 1);
+  [[maybe_unused]] static const int deep = mi_tune("MI_GEMM_XD", 1);
   static const int roles = mi_tune("MI_GEMM_XW", 1);    // 0: fp8_gemm_xd_kernel; bit 1 set: per-lane epilogue
   const int staged = (roles & 2) == 0 && I % 16 == 0 && ((uintptr_t)q_out & 15) == 0;
-#define LAUNCH_EPI(TT, MTV)                                                                                    \
-  if (roles) fp8_gemm_xw_kernel<TT, MTV, 1, 4><<<grid, 512, xw_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
-  else if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
+#ifdef MI_TUNING
+#define LAUNCH_EPI_LEGACY(TT, MTV)                                                                             \
+  if (deep == 5) fp8_gemm_xd_kernel<TT, MTV, 1, 5><<<grid, 512, xd_lds(MTV, 5), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else if (deep) fp8_gemm_xd_kernel<TT, MTV, 1, 4><<<grid, 512, xd_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi); \
   else fp8_gemm_xs_kernel<TT, MTV, 8, 5, 1><<<grid, 512, xs_split_lds(MTV), st>>>(p, nullptr, 1, ppw, 0, epi)
+#else
+#define LAUNCH_EPI_LEGACY(TT, MTV) return 1
+#endif
+#define LAUNCH_EPI(TT, MTV)                                                                                    \
+  if (roles) fp8_gemm_xw_kernel<TT, MTV, 1, 4><<<grid, 512, xw_lds(MTV, 4), st>>>(p, nullptr, 1, 2 * ppw, 0, epi, staged); \
+  else LAUNCH_EPI_LEGACY(TT, MTV)
   if (dtype == MI_BF16) {
     if (M <= 16) LAUNCH_EPI(bf16_t, 1); else if (M <= 32) LAUNCH_EPI(bf16_t, 2); else if (M <= 64) LAUNCH_EPI(bf16_t, 4); else if (M <= 128) LAUNCH_EPI(bf16_t, 8);
     else fp8_gemm_xd_kernel<bf16_t, 16, 1, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, nullptr, 1, 2 * ppw, 0, epi);
@@ -1947,6 +1931,7 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
     else fp8_gemm_xd_kernel<f16_t, 16, 1, 3><<<grid, 512, xd_lds(16, 3), st>>>(p, nullptr, 1, 2 * ppw, 0, epi);
   }
 #undef LAUNCH_EPI
+#undef LAUNCH_EPI_LEGACY
   MI_CHECK_LAUNCH();
   return MI_OK;
 }
