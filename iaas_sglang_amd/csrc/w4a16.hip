@@ -922,12 +922,14 @@ static bool w4_xw_plan(int64_t M, int64_t N, int64_t K, int64_t group, int* S, i
   const int64_t nph = K / 128, rows = M <= 16 ? 16 : M <= 32 ? 32 : M <= 64 ? 64 : 128;
   double best = 0;
   bool found = false;
+  static const int force_nt = mi_tune("MI_W4_NT", 0), force_s = mi_tune("MI_W4_S", 0);   // tuning builds: sweep the plan
   for (int nt = 4; nt >= 1; nt >>= 1) {
     const int64_t wr = 64 * nt;
-    if (N % wr != 0) continue;
+    if (N % wr != 0 || (force_nt && nt != force_nt)) continue;
     if (rows * 256 + nt * 4096 + 1024 > 160 * 1024 / 3) continue;         // three stages must fit
     const int64_t nblk = N / wr;
     int64_t want = nblk >= 200 ? 1 : 256 / nblk;
+    if (force_s) want = force_s;
     if (want < 1) want = 1;
     if (want > nph) want = nph;
     const int64_t per = cdiv64(nph, want), s = cdiv64(nph, per);
