@@ -372,15 +372,18 @@ __global__ __launch_bounds__(NWV * 64) void w4a16_xs_kernel(const W4Params p, fl
 // What the stamps of the FP8 kernel showed applies here more strongly: in w4a16_xs_kernel every one of 8 waves issues
 // DMA, reads the WHOLE activation stage (8 x 16 KiB at M = 64 for 8 KiB of packed weights), dequantises and runs its
 // MFMAs in lock-step (measured: 0.14 of the HBM rate at the C4 shapes, SQ_WAIT_ANY 0.44-0.49, MFMA 0.08-0.12 busy).
-//   * waves 4-7 are LOADERS (LDS-DMA only: activation pieces of 4 rows x 256 B, the 1-KiB native weight tiles, one
+//   * waves 8-11 are LOADERS (LDS-DMA only: activation pieces of 4 rows x 256 B, the 1-KiB native weight tiles, one
 //     1-KiB row of (scale, zero) words per 128-k phase), counted vmcnt, one barrier per phase, phases walked cyclically
 //     from (7 b) % count in workgroup b;
-//   * waves 0-3 are CONSUMERS, one per SIMD, each owning NT 16-column tiles x all M rows: an activation fragment feeds
-//     NT MFMAs (NT = 4: a quarter of the fragment reads per flop), and the workgroup's 64 NT columns share one pass
-//     over the activations -- at fp16/bf16 activations against int4 weights the ACTIVATION block is most of what a CU
-//     ingests ((M x 256 B) per phase against NT x 4 KiB of weights), so wide column blocks + split-K beat 128-column
-//     blocks (w4_xw_plan);
-//   * the epilogue goes through LDS: whole-row stores of the fp32 slab tile or of the T-typed output by all 8 waves.
+//   * waves 0-7 are CONSUMERS, two per SIMD (with one per SIMD the dequant VALU of a wave and its own MFMAs do not
+//     overlap: 30.5 us for gate_up against 26.1 with two), each owning NT/2 16-column tiles x all M rows of the
+//     workgroup's 64 NT columns: an activation fragment feeds NT/2 MFMAs, and the block shares one pass over the
+//     activations -- at fp16/bf16 activations against int4 weights the ACTIVATION block is most of what a CU ingests
+//     ((M x 256 B) per phase against NT x 4 KiB of weights), so wide column blocks + split-K beat 128-column blocks
+//     (w4_xw_plan);
+//   * the dequantisation of step s + 1 is placed by hand between the MFMAs of step s (one quarter of a fragment per
+//     MFMA, DeqQ<T>): left to the scheduler each step's dequant sits in one block in front of its MFMAs;
+//   * the epilogue goes through LDS: whole-row stores of the fp32 slab tile or of the T-typed output by all 12 waves.
 // Dequant, MFMA operands and the per-element accumulation order over a workgroup's phases are those of
 // w4a16_xs_kernel up to the rotation of the phase walk (fp32 sums of the same terms in another order).
 #ifdef MI_TUNING
