@@ -250,8 +250,10 @@ def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, chunk=16)
         chunks.append(n)
         done += n
 
-    def run(n, seed):
-        fb = H.make_extend_batch(runner, backend, [0] * n, [S] * n, dev, seed=seed)
+    def run(n, seed, first_req):
+        # chunk i: request rows first_req .. first_req + n - 1, its own slot range of the pool, its own activations
+        fb = H.make_extend_batch(runner, backend, [0] * n, [S] * n, dev, seed=seed, req_offset=first_req,
+                                 slot_offset=first_req * S)
         hidden = torch.randn(n * S, shape.hidden, device=dev, dtype=torch.float32).to(stack.dtype)
         return fb, hidden
 
@@ -259,12 +261,17 @@ def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, chunk=16)
         backend.init_forward_metadata(fb)
         return stack.forward(hidden, fb.positions, fb, backend, last_token_logits=fb.extend_seq_lens)
 
-    batches = {n: run(n, 3 + n) for n in sorted(set(chunks))}
-    forward(*batches[chunks[0]])
+    warm = run(chunks[0], 99, 0)             # one untimed chunk (lazy inits, scratch growth)
+    forward(*warm)
+    del warm
+    batches, first = [], 0
+    for i, n in enumerate(chunks):          # DISTINCT chunks: the stack updates `hidden` in place (residual stream)
+        batches.append(run(n, 3 + i, first))
+        first += n
     barrier_sync(world)
     t0 = time.perf_counter()
-    for n in chunks:
-        forward(*batches[n])
+    for b in batches:
+        forward(*b)
     barrier_sync(world)
     sec = time.perf_counter() - t0
     T = nseq * S
@@ -282,7 +289,7 @@ def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, chunk=16)
                          "frac": round(ideal / sec, 4),
                          "note": "peak = flops / (fp8 linear flops at 5 PF + bf16 attention and lm_head flops at 2.5 PF per GPU)"},
             "sample": f"{nseq} sequences x {S} tokens = the metric's batch, no prefix, {shape.layers} layers, eager, "
-                      f"{len(chunks)} EXTEND batches of {chunk} sequences; "
+                      f"{len(chunks)} DISTINCT EXTEND batches of {chunk} sequences (own request rows, pool slots and activations); "
                       f"flops = linears {lin:.3e} + causal attention {attn:.3e} + lm_head {head:.3e}"}
 
 

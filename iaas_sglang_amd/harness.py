@@ -505,24 +505,24 @@ def make_decode_batch(runner, backend, batch, seq_len, device, scattered=True, s
     return fb
 
 
-def make_extend_batch(runner, backend, prefix_lens, extend_lens, device, seed=0):
+def make_extend_batch(runner, backend, prefix_lens, extend_lens, device, seed=0, req_offset=0, slot_offset=0):
     """An EXTEND ForwardBatch (schedule_batch.py:1119-1309): prefix slots already in req_to_token,
     new tokens get fresh slots written to req_to_token[pre:seq] and out_cache_loc."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     B = len(prefix_lens)
     lens = [p + e for p, e in zip(prefix_lens, extend_lens)]
     total = sum(lens)
-    assert total <= runner.token_to_kv_pool.size
-    slots = torch.randperm(total, generator=g) + 1
+    assert slot_offset + total <= runner.token_to_kv_pool.size
+    slots = torch.randperm(total, generator=g) + 1 + slot_offset     # request rows req_offset.., a slot range of its own
     r2t = runner.req_to_token_pool.req_to_token
     off, out_loc, pos = 0, [], []
     for i in range(B):
-        r2t[i, : lens[i]] = slots[off: off + lens[i]].to(torch.int32).to(device)
+        r2t[req_offset + i, : lens[i]] = slots[off: off + lens[i]].to(torch.int32).to(device)
         out_loc.append(slots[off + prefix_lens[i]: off + lens[i]])
         pos.append(torch.arange(prefix_lens[i], lens[i]))
         off += lens[i]
     return SimpleNamespace(forward_mode=ForwardMode.EXTEND, batch_size=B,
-                           req_pool_indices=torch.arange(B, dtype=torch.int64, device=device),
+                           req_pool_indices=torch.arange(req_offset, req_offset + B, dtype=torch.int64, device=device),
                            seq_lens=torch.tensor(lens, dtype=torch.int64, device=device), seq_lens_sum=total,
                            seq_lens_cpu=torch.tensor(lens, dtype=torch.int64),
                            extend_prefix_lens=torch.tensor(prefix_lens, dtype=torch.int32, device=device),
