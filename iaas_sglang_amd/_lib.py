@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_hotpath.so")
 
-ABI_VERSION = 8          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
+ABI_VERSION = 9          # MI_ABI_VERSION of include/mi_hotpath.h this table was written against
 MI_BF16, MI_FP16, MI_F32 = 0, 1, 2
 MI_SCALE_TENSOR, MI_SCALE_ROW = 0, 1
 MI_W4_AWQ, MI_W4_GPTQ = 0, 1
@@ -46,6 +46,7 @@ SIGNATURES = {
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_paged": (_int, [_p] * 11 + [_i64] * 12 + [_f, _f, _int, _i64, _int, _p]),
+    "mi_extend_attn_fp8out": (_int, [_p] * 13 + [_i64] * 13 + [_f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_splitkv": (_int, [_p] * 6 + [_int, _f, _f] + [_p] * 5 + [_int] + [_i64] * 11 + [_f, _f, _int, _i64, _p, _i64, _i64,

@@ -644,14 +644,40 @@ class MiAttnBackend(AttentionBackend):
                              split_chunk=md.split_chunk, work=md.work)
         return o
 
-    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True, fp8_out_scale=None):
+        """`fp8_out_scale` (extension, as in forward_decode): the static input scale of the following FP8 linear; the
+        output is then returned already quantised (fp8 [tokens, Hq * Dv]), bit-identical to quantising the T-typed
+        result.  Long extends write it from the attention epilogue (mi_extend_attn_fp8out); the speculative / split /
+        fp8-pool forms quantise their T-typed output in a second launch."""
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("MiAttnBackend: qk_head_dim != v_head_dim (MLA) is out of scope")
-        o = q.new_empty(q.shape)
         if save_kv_cache:
             self._save_kv(forward_batch, layer, k, v)
         k_buf, v_buf = self._pool_buffers(forward_batch, layer)
         md = self.forward_metadata
+        if fp8_out_scale is not None:
+            cap = getattr(layer, "logit_cap", 0.0) or 0.0
+            window = getattr(layer, "sliding_window_size", -1)
+            window = -1 if window is None else int(window)
+            plain = md.num_kv_splits <= 1 and md.custom_mask is None and k_buf.element_size() != 1
+            if not plain:
+                o = self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=False)
+                return ops.fp8_quant_per_tensor(o, fp8_out_scale)[0]
+            causal = not (getattr(layer, "is_cross_attention", False)
+                          or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
+            fused = ops.extend_fp8_out_is_fused(layer.qk_head_dim, md.max_extend_len, cap, window)
+            o = None if fused else q.new_empty(q.shape)
+            o8 = torch.empty(q.shape, dtype=ops.FP8_DTYPE, device=q.device)
+            ops.extend_attention_fp8out(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                                        k.reshape(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                                        v.reshape(-1, layer.tp_v_head_num, layer.v_head_dim), o8, fp8_out_scale, k_buf,
+                                        v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices, md.max_extend_len,
+                                        layer.scaling, cap, causal, window if window > 0 else -1,
+                                        md.page_indptr, md.page_indices if md.page_indptr is not None else None,
+                                        md.page_size if md.page_indptr is not None else 1,
+                                        None if o is None else o.view(-1, layer.tp_q_head_num, layer.v_head_dim))
+            return o8
+        o = q.new_empty(q.shape)
         causal = not (getattr(layer, "is_cross_attention", False)
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")
         window = getattr(layer, "sliding_window_size", -1)

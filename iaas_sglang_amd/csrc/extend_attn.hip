@@ -54,7 +54,21 @@ struct ExtendParams {
   const int32_t* page_indptr;
   const int32_t* page_indices;
   int32_t page_shift;
+  // optional fp8 copy of the output (extend_attn32_kernel only): o_q [tokens][Hq * D] contiguous e4m3fn =
+  // quant(T-rounded o, *o_qscale), the static input scale of the following FP8 linear (o_proj); `o` may then be null
+  uint8_t* o_q;
+  const float* o_qscale;
 };
+
+// T-rounded values -> e4m3fn with a static scale (the arithmetic of quant_tensor_kernel mode 1, fp8_quant.hip, and of
+// the decode kernels' fp8 output, decode_attn.hip)
+template <typename T> __device__ __forceinline__ uint32_t x_quant4_static(float a, float b, float c, float d, float inv) {
+  auto f = [inv](float v) { return fmaxf(fminf(round_to<T>(v) * inv, 448.0f), -448.0f); };
+  uint32_t w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f(a), f(b), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f(c), f(d), w, true);
+  return w;
+}
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -659,22 +673,48 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   if (wave_active) {
     const float inv = 1.f / lsum;
     char* stg = smem + wave * 8192;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *(uint2*)(stg + 256 * r + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) =
-            make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
-                       pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
-    const int pr = lane >> 4, pc = lane & 15;
     typedef __attribute__((ext_vector_type(4))) uint32_t st_u32x4;
+    if (p.o) {
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int row = ps * 4 + pr;
-      const uint4 v = *(const uint4*)(stg + 256 * row + ((pc ^ (row & 15)) << 4));
-      if (tok0 + row < ext_len)
-        __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w},
-                                    (st_u32x4*)((T*)p.o + (int64_t)(q_start + tok0 + row) * p.stride_o_tok + (int64_t)head * D + 8 * pc));
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(uint2*)(stg + 256 * r + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) =
+              make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
+                         pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
+      const int pr = lane >> 4, pc = lane & 15;
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 4 + pr;
+        const uint4 v = *(const uint4*)(stg + 256 * row + ((pc ^ (row & 15)) << 4));
+        if (tok0 + row < ext_len)
+          __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w},
+                                      (st_u32x4*)((T*)p.o + (int64_t)(q_start + tok0 + row) * p.stride_o_tok + (int64_t)head * D + 8 * pc));
+      }
+    }
+    if (p.o_q) {
+      // fp8 copy for the following FP8 linear (static input scale): the same T-rounded values, quantised as
+      // mi_fp8_quant_per_tensor(static) would -- the separate quant launch and its read of `o` disappear.  Staged in
+      // the same wave-private 8 KiB (LDS operations of one wave execute in order: the reads above are done) as
+      // [32 rows][128 B], row pitch 144 B, and stored as whole 128-byte head rows, 8 rows per instruction.
+      const float qs = *p.o_qscale;
+      const float qinv = qs > 0.f ? 1.0f / qs : 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(uint32_t*)(stg + 144 * r + 32 * db + 8 * g + 4 * h) =
+              x_quant4_static<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv, acc[db][4 * g + 2] * inv,
+                                 acc[db][4 * g + 3] * inv, qinv);
+      const int qr = lane >> 3, qc = lane & 7;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + qr;
+        const uint4 v = *(const uint4*)(stg + 144 * row + 16 * qc);
+        if (tok0 + row < ext_len)
+          __builtin_nontemporal_store(st_u32x4{v.x, v.y, v.z, v.w},
+                                      (st_u32x4*)(p.o_q + ((int64_t)(q_start + tok0 + row) * p.num_q_heads + head) * D + 16 * qc));
+      }
     }
   }
   __syncthreads();     // the staged outputs have been read: the next item may fill the stage buffers
@@ -759,10 +799,12 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
                             const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
                             int skip_prefix_mask = 1, void* workspace = nullptr, int64_t total_tokens = 0,
                             int64_t num_splits = 1, const int32_t* page_indptr = nullptr,
-                            const int32_t* page_indices = nullptr, int64_t page_size = 1) {
+                            const int32_t* page_indices = nullptr, int64_t page_size = 1, void* o_fp8 = nullptr,
+                            const float* o_scale = nullptr) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
-  MI_CHECK_ARG(q_ext && k_ext && v_ext && o_ext && qo_indptr && kv_indptr);
+  MI_CHECK_ARG(q_ext && k_ext && v_ext && (o_ext || o_fp8) && qo_indptr && kv_indptr);
+  MI_CHECK_ARG(!o_fp8 || (o_scale && ((uintptr_t)o_fp8 & 15) == 0 && num_splits == 1));
   MI_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
   MI_CHECK_ARG(num_splits >= 1 && num_splits <= 64 && batch * num_splits <= 65535);
   // one-dimensional launches: (q blocks of >= 16 rows) x heads x (requests x splits) workgroups
@@ -795,7 +837,16 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   }
   p.ws_o = (float*)workspace;
   p.ws_ml = p.ws_o ? p.ws_o + total_tokens * num_q_heads * num_splits * head_dim : nullptr;
+  p.o_q = (uint8_t*)o_fp8; p.o_qscale = o_scale;
   hipStream_t st = (hipStream_t)stream;
+  if (o_fp8) {
+    // the fp8 output exists in the long-extend kernel only; its caller checked the preconditions (mi_extend_attn_fp8out)
+    const bool ok = dtype == MI_BF16 ? try_launch_extend32<bf16_t>(p, batch, max_extend_len, st)
+                                     : try_launch_extend32<f16_t>(p, batch, max_extend_len, st);
+    if (!ok) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_extend_attn_fp8out: shape not served by the long-extend kernel");
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+  }
   if (kv8) {
     MI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
     if (head_dim != 128) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_extend_attn_fp8kv: head_dim 128 only");
@@ -889,4 +940,40 @@ extern "C" int mi_extend_attn_masked(const void* q_ext, const void* k_ext, const
                           num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok, stride_vx_tok,
                           stride_k_slot, stride_v_slot, sm_scale, logit_cap, 0, sliding_window, dtype, stream, false, 1.f,
                           1.f, custom_mask, mask_indptr, skip_prefix_custom_mask);
+}
+
+// mi_extend_attn (token- or page-granular prefix) with the output ALSO / ONLY as e4m3fn for the FP8 linear that follows
+// (o_proj with a static input scale; prefill's form of mi_decode_attn_fp8out): o_fp8 [tokens, Hq * D] contiguous =
+// mi_fp8_quant_per_tensor(static, *o_scale) of the T-typed result, bit for bit; o_ext may be null.  The long-extend
+// kernel (head_dim 128, bf16 / fp16 pool, extends >= 64 tokens, no mask / window / cap) writes it from its epilogue;
+// for every other shape the T-typed kernel runs into o_ext (then required) and the quantisation is a second launch.
+extern "C" int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext /* nullable */,
+                                     void* o_fp8, const float* o_scale, const void* k_buf, const void* v_buf,
+                                     const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                     const int32_t* page_indptr /* nullable */, const int32_t* page_indices /* nullable */,
+                                     int64_t page_size, int64_t batch, int64_t total_tokens, int64_t max_extend_len,
+                                     int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                                     int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok,
+                                     int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
+                                     int causal, int64_t sliding_window, int dtype, void* stream) {
+  MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr && total_tokens >= 0);
+  MI_CHECK_ARG((page_indptr == nullptr) == (page_indices == nullptr));
+  static const int enable32 = mi_tune("MI_EXTEND_32", 1);
+  const bool fused = enable32 && head_dim == 128 && max_extend_len >= 64 && sliding_window <= 0 && !(logit_cap > 0.f) &&
+                     stride_o_tok % 8 == 0 && ((uintptr_t)o_ext & 15) == 0;
+  if (fused)
+    return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch,
+                            max_extend_len, num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok,
+                            stride_vx_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype,
+                            stream, false, 1.f, 1.f, nullptr, nullptr, 1, nullptr, 0, 1, page_indptr, page_indices,
+                            page_indptr ? page_size : 1, o_fp8, o_scale);
+  if (!o_ext) MI_FAIL(MI_ERR_INVALID, "mi_extend_attn_fp8out: this shape needs the T-typed output buffer o_ext as well");
+  const int rc = extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch,
+                                  max_extend_len, num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok,
+                                  stride_kx_tok, stride_vx_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal,
+                                  sliding_window, dtype, stream, false, 1.f, 1.f, nullptr, nullptr, 1, nullptr, 0, 1,
+                                  page_indptr, page_indices, page_indptr ? page_size : 1);
+  if (rc != MI_OK) return rc;
+  return mi_fp8_quant_per_tensor(o_ext, o_fp8, const_cast<float*>(o_scale), total_tokens, num_q_heads * head_dim,
+                                 stride_o_tok, 1, dtype, stream);
 }

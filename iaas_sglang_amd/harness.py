@@ -417,9 +417,15 @@ class LlamaStack:
                 qkv = L.qkv(x)
             q, k, v = qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size], qkv[:, self.q_size + self.kv_size:]
             ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
-            a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
-                                L.attn, fb)
-            hidden = self._all_reduce(L.o(a))
+            qs_o = L.o.fused_quant_scale()
+            if qs_o is not None:     # attention hands o_proj its fp8 input (decode: the split merge; extend: the epilogue)
+                a8 = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
+                                     L.attn, fb, fp8_out_scale=qs_o)
+                hidden = self._all_reduce(L.o.forward_prequantized(a8, self.dtype))
+            else:
+                a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
+                                    L.attn, fb)
+                hidden = self._all_reduce(L.o(a))
             qs = L.gate_up.fused_quant_scale()
             qs_down = L.down.fused_quant_scale()
             silu_ok = getattr(L.gate_up.quant_method, "fused_silu_ok", None)

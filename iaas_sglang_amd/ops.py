@@ -304,6 +304,42 @@ def extend_attention_paged(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Te
     return o
 
 
+def extend_attention_fp8out(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o_fp8: torch.Tensor,
+                            o_scale: torch.Tensor, k_buf: torch.Tensor, v_buf: torch.Tensor, qo_indptr: torch.Tensor,
+                            kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, max_extend_len: int, sm_scale: float,
+                            logit_cap: float = 0.0, causal: bool = True, sliding_window: int = -1,
+                            page_indptr: Optional[torch.Tensor] = None, page_indices: Optional[torch.Tensor] = None,
+                            page_size: int = 1, o: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """extend_attention (token- or page-granular prefix) returning the output quantised for the following FP8 linear:
+    o_fp8 [E, Hq * D] e4m3fn = fp8_quant_per_tensor(static, o_scale) of the T-typed result, bit for bit.  `o`
+    (optional [E, Hq, D]) also receives the T-typed result; it is REQUIRED for the shapes the long-extend kernel does
+    not take (fp8_out_is_fused says which), where the quantisation is a second launch."""
+    E, Hq, D = q.shape
+    Hkv = k_ext.shape[1]
+    B = qo_indptr.shape[0] - 1
+    for t in (q, k_ext, v_ext, k_buf, v_buf) + ((o,) if o is not None else ()):
+        assert t.stride(2) == 1 and t.stride(1) == D and t.dtype == q.dtype
+    assert o_fp8.element_size() == 1 and o_fp8.is_contiguous() and o_fp8.numel() == E * Hq * D
+    assert o_scale.dtype == torch.float32 and o_scale.numel() >= 1
+    for t in (qo_indptr, kv_indptr_t, kv_indices_t):
+        assert t.dtype == torch.int32
+    assert (page_indptr is None) == (page_indices is None)
+    check(lib.mi_extend_attn_fp8out(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o) if o is not None else None, _ptr(o_fp8),
+                                    _ptr(o_scale), _ptr(k_buf), _ptr(v_buf), _ptr(qo_indptr), _ptr(kv_indptr_t),
+                                    _ptr(kv_indices_t), _ptr(page_indptr) if page_indptr is not None else None,
+                                    _ptr(page_indices) if page_indices is not None else None, int(page_size), B, E,
+                                    int(max_extend_len), Hq, Hkv, D, q.stride(0), o.stride(0) if o is not None else Hq * D,
+                                    k_ext.stride(0), v_ext.stride(0), k_buf.stride(0), v_buf.stride(0), float(sm_scale),
+                                    float(logit_cap), int(causal), int(sliding_window), _dt(q), _stream()),
+          "mi_extend_attn_fp8out")
+    return o_fp8
+
+
+def extend_fp8_out_is_fused(head_dim: int, max_extend_len: int, logit_cap: float, sliding_window: int) -> bool:
+    """True when mi_extend_attn_fp8out writes the fp8 output from the attention epilogue (no T-typed buffer needed)."""
+    return head_dim == 128 and max_extend_len >= 64 and not (logit_cap > 0.0) and sliding_window <= 0
+
+
 def extend_attention_fp8kv(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.Tensor, o: torch.Tensor,
                            k_buf8: torch.Tensor, v_buf8: torch.Tensor, k_scale: float, v_scale: float,
                            qo_indptr: torch.Tensor, kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor,

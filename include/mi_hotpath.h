@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 8
+#define MI_ABI_VERSION 9
 
 enum { MI_BF16 = 0, MI_FP16 = 1, MI_F32 = 2 };
 enum {
@@ -220,6 +220,24 @@ int mi_extend_attn_paged(const void* q_ext, const void* k_ext, const void* v_ext
                          int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
                          int64_t stride_v_slot, float sm_scale, float logit_cap, int causal,
                          int64_t sliding_window, int dtype, void* stream);
+
+/* mi_extend_attn / mi_extend_attn_paged with the output ALSO (o_ext given) or ONLY (o_ext null) as e4m3fn for the FP8
+ * linear that follows -- prefill's form of mi_decode_attn_fp8out: o_fp8 [total_tokens, num_q_heads * head_dim] contiguous =
+ * mi_fp8_quant_per_tensor(mode 1, *o_scale) of the T-typed result, bit for bit.  The long-extend kernel (head_dim 128,
+ * bf16 / fp16 pool, max_extend_len >= 64, no window / cap) writes it from its epilogue; every other shape runs the
+ * T-typed kernel into o_ext (then required: MI_ERR_INVALID without it) and quantises in a second launch.  page_indptr /
+ * page_indices: both null (token-granular prefix) or both given (as mi_extend_attn_paged).
+ * replaces: extend_attention_fwd (extend_attention.py:306-438) followed by static_quant_fp8 in apply_fp8_linear
+ * (fp8_utils.py:654-660) of the o_proj RowParallelLinear (models/llama.py:186-190). */
+int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext /* nullable */,
+                          void* o_fp8, const float* o_scale, const void* k_buf, const void* v_buf,
+                          const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                          const int32_t* page_indptr /* nullable */, const int32_t* page_indices /* nullable */,
+                          int64_t page_size, int64_t batch, int64_t total_tokens, int64_t max_extend_len,
+                          int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
+                          int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
+                          int64_t stride_v_slot, float sm_scale, float logit_cap, int causal, int64_t sliding_window,
+                          int dtype, void* stream);
 
 /* mi_extend_attn whose cached PREFIX lives in an fp8 (e4m3fn) pool: k_buf8/v_buf8 hold bytes, stride_*_slot in
  * BYTES, head_dim 128; prefix keys are k8 * k_scale, prefix values v8 * v_scale (converted while being staged);

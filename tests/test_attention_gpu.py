@@ -990,3 +990,50 @@ def test_backend_extend_on_a_paged_pool_uses_page_tables(page_size):
     ref = oa.extend_fp32(q.view(-1, Hq, D), kc, vc, r2t.cpu(), torch.arange(3), torch.tensor(lens), torch.tensor(pre),
                          torch.tensor(ext), scaling=D ** -0.5, causal=True)
     torch.testing.assert_close(o.view(-1, Hq, D).cpu().float(), ref, atol=4e-3, rtol=2 ** -6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("pre,ext,paged", [
+    ([0] * 3, [2048, 300, 64], False),                       # long extends, no prefix: the epilogue writes the fp8 rows
+    ([1024, 17, 0, 640], [256, 1000, 65, 129], True),        # page-granular prefix, ragged tails inside a 32-row block
+    ([512, 0], [40, 63], False),                             # short extends: T-typed kernel + quant launch (o required)
+])
+def test_extend_fp8_output_is_bit_identical_to_extend_then_static_quant(dtype, pre, ext, paged):
+    """mi_extend_attn_fp8out (prefill's form of mi_decode_attn_fp8out: the o_proj input quantised by the attention
+    kernel) against mi_extend_attn[_paged] followed by mi_fp8_quant_per_tensor(static): the same bytes; with `o` given
+    the T-typed result equals the plain call too."""
+    from iaas_sglang_amd import ops
+    page_size = 16
+    g = torch.Generator().manual_seed(11 + len(pre))
+    q, kn, vn, kc, vc, qop, kvp, idx, pi, px = _paged_prefix_case(g, pre, ext, page_size)
+    q, kn, vn, kc, vc = (t.to(dtype) for t in (q, kn, vn, kc, vc))
+    E, Hq, D = q.shape
+    scale = torch.tensor([0.0123], dtype=torch.float32, device=DEV)
+    ref = torch.empty_like(q)
+    if paged:
+        ops.extend_attention_paged(q, kn, vn, ref, kc, vc, qop, kvp, idx, pi, px, page_size, max(ext), D ** -0.5, 0.0, True, -1)
+    else:
+        ops.extend_attention(q, kn, vn, ref, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1)
+    ref8, _ = ops.fp8_quant_per_tensor(ref.view(E, Hq * D), scale)
+    fused = ops.extend_fp8_out_is_fused(D, max(ext), 0.0, -1)
+    assert fused == (max(ext) >= 64)
+    pargs = dict(page_indptr=pi, page_indices=px, page_size=page_size) if paged else {}
+    # fp8 only (where the kernel writes it itself), and fp8 + T-typed output
+    outs = []
+    if fused:
+        o8 = torch.full((E, Hq * D), 0x7f, dtype=torch.uint8, device=DEV).view(ops.FP8_DTYPE)
+        ops.extend_attention_fp8out(q, kn, vn, o8, scale, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1, **pargs)
+        outs.append((o8, None))
+    else:
+        with pytest.raises(RuntimeError):
+            ops.extend_attention_fp8out(q, kn, vn, torch.empty(E, Hq * D, dtype=ops.FP8_DTYPE, device=DEV), scale, kc, vc,
+                                        qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1, **pargs)
+    o8 = torch.full((E, Hq * D), 0x7f, dtype=torch.uint8, device=DEV).view(ops.FP8_DTYPE)
+    o = torch.empty_like(q)
+    ops.extend_attention_fp8out(q, kn, vn, o8, scale, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1, o=o, **pargs)
+    outs.append((o8, o))
+    torch.cuda.synchronize()
+    for o8, o in outs:
+        assert torch.equal(o8.view(torch.uint8), ref8.view(torch.uint8))
+        if o is not None:
+            assert torch.equal(o.view(torch.int16), ref.view(torch.int16))

@@ -17,6 +17,13 @@ contig = os.environ.get("CONTIG", "0") == "1"
 slots = B * S + 1
 pools = [(torch.randn(slots, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16),
           torch.randn(slots, Hkv, D, device=dev, dtype=torch.float32).to(torch.bfloat16)) for _ in range(npool)]
+if os.environ.get("VOFF") is not None:      # K and V carved out of ONE allocation, V shifted by VOFF bytes past the end of K:
+    voff = int(os.environ["VOFF"]) // 2      # does the relative placement of the two buffers (memory channels) matter?
+    n = slots * Hkv * D
+    pools = []
+    for _ in range(npool):
+        big = torch.randn(2 * n + voff + 64, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        pools.append((big[:n].view(slots, Hkv, D), big[n + voff: 2 * n + voff].view(slots, Hkv, D)))
 q = torch.randn(B, Hq, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
 o = torch.empty_like(q)
 g = torch.Generator(device=dev).manual_seed(0)
