@@ -87,6 +87,7 @@ SIGNATURES = {
                                            _p, _i64, _p]),
     "mi_fp8_gemm_rope_kvwrite": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,
                                         _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
+    "mi_fp8_gemm_qkv_rope_kvwrite": (_int, [_p] * 10 + [_i64] * 10 + [_int, _p]),
     "mi_fp8_gemm_silu_mul_fp8": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mi_gather_columns": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "mi_w4_dequantize_native": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),

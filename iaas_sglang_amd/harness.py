@@ -408,23 +408,34 @@ class LlamaStack:
             if first:
                 residual = hidden
             qs = L.qkv.fused_quant_scale()
+            kv_saved = False
             if qs is not None:
-                qkv = L.qkv.forward_prequantized(
-                    ops.rmsnorm_fp8(hidden, L.input_norm, s.rms_eps, qs, residual=None if first else residual),
-                    self.dtype)
+                qx = ops.rmsnorm_fp8(hidden, L.input_norm, s.rms_eps, qs, residual=None if first else residual)
+                qkv = None
+                fuse = getattr(L.qkv.quant_method, "apply_qkv_rope_kvwrite", None)
+                pool = fb.token_to_kv_pool
+                if (fuse is not None and LlamaStack.fuse_decode_layer and fb.forward_mode.is_extend()
+                        and pool.get_key_buffer(L.attn.layer_id).dtype == self.dtype):
+                    # prefill: RoPE and the KV-pool write ride in the qkv GEMM's epilogue (None: no fused form here)
+                    qkv = fuse(L.qkv, qx, positions, self.cos_sin, pool.get_key_buffer(L.attn.layer_id),
+                               pool.get_value_buffer(L.attn.layer_id), fb.out_cache_loc, self.Hq, self.Hkv, s.head_dim)
+                    kv_saved = qkv is not None
+                if qkv is None:
+                    qkv = L.qkv.forward_prequantized(qx, self.dtype)
             else:
                 x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps, residual=None if first else residual)
                 qkv = L.qkv(x)
             q, k, v = qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size], qkv[:, self.q_size + self.kv_size:]
-            ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
+            if not kv_saved:
+                ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
             qs_o = L.o.fused_quant_scale()
             if qs_o is not None:     # attention hands o_proj its fp8 input (decode: the split merge; extend: the epilogue)
                 a8 = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
-                                     L.attn, fb, fp8_out_scale=qs_o)
+                                     L.attn, fb, save_kv_cache=not kv_saved, fp8_out_scale=qs_o)
                 hidden = self._all_reduce(L.o.forward_prequantized(a8, self.dtype))
             else:
                 a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
-                                    L.attn, fb)
+                                    L.attn, fb, save_kv_cache=not kv_saved)
                 hidden = self._all_reduce(L.o(a))
             qs = L.gate_up.fused_quant_scale()
             qs_down = L.down.fused_quant_scale()

@@ -764,6 +764,35 @@ def fp8_gemm_rope_kvwrite(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Te
     return q
 
 
+def fp8_gemm_qkv_rope_kvwrite(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                              positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                              v_cache: torch.Tensor, loc: torch.Tensor, num_q_heads: int, num_kv_heads: int,
+                              head_dim: int) -> Optional[torch.Tensor]:
+    """Prefill form of fp8_gemm_rope_kvwrite: qkv linear of an EXTEND chunk with NeoX RoPE and the KV-pool write in the
+    tile GEMM's epilogue.  Returns qkv [M, (Hq + 2 Hkv) * D] (q, k rotated; v) -- the same bits as fp8_gemm + rope_neox_
+    + kv_write -- or None where no fused form exists (M <= 512, head_dim != 128, or a token count the tile kernel
+    splits over K): the caller then runs the three calls."""
+    _check_fp8_operands(a, b_kn, scale_a, scale_b)
+    M, K = a.shape
+    N = b_kn.shape[1]
+    assert N == (num_q_heads + 2 * num_kv_heads) * head_dim
+    if M <= 512 or head_dim != 128 or N % 256 != 0 or K % 128 != 0 or scale_a.numel() != 1 or scale_b.numel() != 1:
+        return None
+    assert positions.dtype == torch.int64 and loc.dtype == torch.int64 and positions.numel() == M and loc.numel() == M
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim and cos_sin_cache.is_contiguous()
+    assert k_cache.dtype == v_cache.dtype and k_cache[0].is_contiguous() and v_cache[0].is_contiguous()
+    assert k_cache[0].numel() == num_kv_heads * head_dim and v_cache[0].numel() == num_kv_heads * head_dim
+    qkv = torch.empty(M, N, dtype=k_cache.dtype, device=a.device)
+    rc = lib.mi_fp8_gemm_qkv_rope_kvwrite(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(positions),
+                                          _ptr(cos_sin_cache), _ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(loc), M,
+                                          num_q_heads, num_kv_heads, head_dim, K, a.stride(0), b_kn.stride(1),
+                                          qkv.stride(0), k_cache.stride(0), v_cache.stride(0), _dt(k_cache), _stream())
+    if rc == -2:          # MI_ERR_UNSUPPORTED: this token count runs split-K on the tile kernel
+        return None
+    check(rc, "mi_fp8_gemm_qkv_rope_kvwrite")
+    return qkv
+
+
 def fp8_gemm_silu_mul(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
                       q_scale: torch.Tensor, act_dtype: torch.dtype) -> torch.Tensor:
     """gate_up linear + SiLU(gate)*up + static FP8 quant; returns fp8 [M, I]."""

@@ -481,6 +481,20 @@ int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const float* scale
                              int64_t cache_stride_k, int64_t cache_stride_v, int dtype,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Prefill form of mi_fp8_gemm_rope_kvwrite (M > 512 tokens, head_dim 128): the qkv projection on the 256 x 256 tile
+ * kernel with NeoX RoPE and the KV-pool write in its epilogue.  qkv_out [M, (Hq + 2*Hkv)*128] (row pitch ldo) = q and k
+ * ROTATED and v (extend attention reads the new tokens' K / V from there); k_cache / v_cache rows loc[m] = k (rotated) /
+ * v.  Bit-identical to mi_fp8_gemm + mi_rope_neox + mi_kv_write.  MI_ERR_UNSUPPORTED where the tile kernel would split
+ * over K (a few hundred tokens): keep the three calls there.
+ * replaces: apply_fp8_linear (fp8_utils.py:715-723) + RotaryEmbedding.forward_native (rotary_embedding.py:49-166) +
+ * MHATokenToKVPool.set_kv_buffer (memory_pool.py:454-455) of an EXTEND batch. */
+int mi_fp8_gemm_qkv_rope_kvwrite(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                                 const int64_t* positions, const float* cos_sin_cache, void* qkv_out,
+                                 void* k_cache, void* v_cache, const int64_t* loc, int64_t M,
+                                 int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t K,
+                                 int64_t lda, int64_t ldb, int64_t ldo, int64_t cache_stride_k,
+                                 int64_t cache_stride_v, int dtype, void* stream);
+
 /* gate_up = a.b_nk with N = 2*I; q_out [M, I] = fp8(round_T(silu(gate) * up) / *q_scale).  When the GEMM
  * needs no split-K (N large enough to fill the chip) the activation runs in the GEMM's own epilogue and
  * the [M, 2I] intermediate never exists; otherwise through the workspace as above.
