@@ -46,7 +46,7 @@ SIGNATURES = {
     "mi_extend_attn": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                               _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_paged": (_int, [_p] * 11 + [_i64] * 12 + [_f, _f, _int, _i64, _int, _p]),
-    "mi_extend_attn_fp8out": (_int, [_p] * 13 + [_i64] * 13 + [_f, _f, _int, _i64, _int, _p]),
+    "mi_extend_attn_fp8out": (_int, [_p] * 13 + [_i64] * 13 + [_f, _f, _int, _i64, _p, _p, _int, _p]),
     "mi_extend_attn_fp8kv": (_int, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _i64, _f, _f, _int, _i64, _int, _p]),
     "mi_extend_attn_splitkv": (_int, [_p] * 6 + [_int, _f, _f] + [_p] * 5 + [_int] + [_i64] * 11 + [_f, _f, _int, _i64, _p, _i64, _i64,
@@ -87,7 +87,6 @@ SIGNATURES = {
                                            _p, _i64, _p]),
     "mi_fp8_gemm_rope_kvwrite": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64,
                                         _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
-    "mi_fp8_gemm_qkv_rope_kvwrite": (_int, [_p] * 10 + [_i64] * 10 + [_int, _p]),
     "mi_fp8_gemm_silu_mul_fp8": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mi_gather_columns": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "mi_w4_dequantize_native": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),

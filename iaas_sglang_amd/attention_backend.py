@@ -644,11 +644,24 @@ class MiAttnBackend(AttentionBackend):
                              split_chunk=md.split_chunk, work=md.work)
         return o
 
-    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True, fp8_out_scale=None):
+    def extend_rotates_q(self, layer, fp8_out_scale) -> bool:
+        """True when forward_extend(..., fp8_out_scale, q_rope=...) can rotate Q inside the attention kernel for the
+        metadata at hand (long-extend kernel, plain EXTEND batch on a T-typed pool): the caller then runs the rope
+        kernel on k alone (ops.rope_neox_k_)."""
+        md = self.forward_metadata
+        if fp8_out_scale is None or md is None or md.num_kv_splits > 1 or md.custom_mask is not None:
+            return False
+        window = getattr(layer, "sliding_window_size", -1)
+        window = -1 if window is None else int(window)
+        return ops.extend_fp8_out_is_fused(layer.qk_head_dim, md.max_extend_len, getattr(layer, "logit_cap", 0.0) or 0.0,
+                                           window) and layer.qk_head_dim == layer.v_head_dim
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True, fp8_out_scale=None, q_rope=None):
         """`fp8_out_scale` (extension, as in forward_decode): the static input scale of the following FP8 linear; the
         output is then returned already quantised (fp8 [tokens, Hq * Dv]), bit-identical to quantising the T-typed
         result.  Long extends write it from the attention epilogue (mi_extend_attn_fp8out); the speculative / split /
-        fp8-pool forms quantise their T-typed output in a second launch."""
+        fp8-pool forms quantise their T-typed output in a second launch.  `q_rope` = (positions, cos_sin_cache_t): q
+        is unrotated and the kernel applies NeoX RoPE as it loads Q -- only where extend_rotates_q() said so."""
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("MiAttnBackend: qk_head_dim != v_head_dim (MLA) is out of scope")
         if save_kv_cache:
@@ -660,6 +673,8 @@ class MiAttnBackend(AttentionBackend):
             window = getattr(layer, "sliding_window_size", -1)
             window = -1 if window is None else int(window)
             plain = md.num_kv_splits <= 1 and md.custom_mask is None and k_buf.element_size() != 1
+            if q_rope is not None and not (plain and self.extend_rotates_q(layer, fp8_out_scale)):
+                raise ValueError("MiAttnBackend: q_rope on a batch whose attention kernel cannot rotate Q")
             if not plain:
                 o = self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=False)
                 return ops.fp8_quant_per_tensor(o, fp8_out_scale)[0]
@@ -675,8 +690,11 @@ class MiAttnBackend(AttentionBackend):
                                         layer.scaling, cap, causal, window if window > 0 else -1,
                                         md.page_indptr, md.page_indices if md.page_indptr is not None else None,
                                         md.page_size if md.page_indptr is not None else 1,
-                                        None if o is None else o.view(-1, layer.tp_q_head_num, layer.v_head_dim))
+                                        None if o is None else o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                                        None if q_rope is None else q_rope[0], None if q_rope is None else q_rope[1])
             return o8
+        if q_rope is not None:
+            raise ValueError("MiAttnBackend: q_rope needs fp8_out_scale (the fused prefill form)")
         o = q.new_empty(q.shape)
         causal = not (getattr(layer, "is_cross_attention", False)
                       or getattr(getattr(layer, "attn_type", None), "value", "decoder") == "encoder_only")

@@ -58,6 +58,10 @@ struct ExtendParams {
   // quant(T-rounded o, *o_qscale), the static input scale of the following FP8 linear (o_proj); `o` may then be null
   uint8_t* o_q;
   const float* o_qscale;
+  // optional NeoX RoPE of Q on load (extend_attn32_kernel only; the caller then runs mi_rope_neox on k alone):
+  // q_positions [tokens] and the rotary cache [max_pos][128] rounded to T
+  const int64_t* q_positions;
+  const void* q_rope_t;
 };
 
 // T-rounded values -> e4m3fn with a static scale (the arithmetic of quant_tensor_kernel mode 1, fp8_quant.hip, and of
@@ -446,6 +450,8 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
 
   // Q fragments (B operand of S^T = K . Q^T): lane -> query row r, dims 16 kk + 8 h .. + 8
   vec8 qf[8];
+  // (requested with the Q rows: back by the time the first K / V tile's loads have been issued, see the rotation below)
+  const int64_t rope_pos = p.q_rope_t ? p.q_positions[q_start + my_tok] : 0;
   {
     const T* qp = (const T*)p.q + (int64_t)(q_start + my_tok) * p.stride_q_tok + (int64_t)head * D + 8 * h;
 #pragma unroll
@@ -526,6 +532,38 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   }
 
   X32_STAGE_LOAD(0);
+  // (Q rotation sits here so that its position -> cos / sin round trips run under the first K / V tile's loads; in front
+  // of them it added ~3 us of exposed latency to every work item: 16 x 2048 causal 0.78 -> 0.86 ms)
+  if (p.q_rope_t) {
+    // NeoX RoPE in registers, rope_neox_kernel's arithmetic (elementwise.hip: cos / sin as T, every product and sum
+    // rounded to T): fragment kk < 4 holds x1 = dims 16 kk + 8 h .. + 8 and fragment kk + 4 their partners x2 = + 64.
+    // Once per (query block, head): the rope kernel's read + write of q (536 MB per 32 k tokens) disappears.
+    const T* cs = (const T*)p.q_rope_t + rope_pos * 128 + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint4 cw4 = *(const uint4*)(cs + 16 * kk), sw4 = *(const uint4*)(cs + 64 + 16 * kk);
+      const uint4 a4 = __builtin_bit_cast(uint4, qf[kk]), b4 = __builtin_bit_cast(uint4, qf[kk + 4]);
+      const uint32_t cw[4] = {cw4.x, cw4.y, cw4.z, cw4.w}, sw[4] = {sw4.x, sw4.y, sw4.z, sw4.w};
+      const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+      uint32_t r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float o1[2], o2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float x1 = t ? Elem<T>::hi(aw[e]) : Elem<T>::lo(aw[e]), x2 = t ? Elem<T>::hi(bw[e]) : Elem<T>::lo(bw[e]);
+          const float co = t ? Elem<T>::hi(cw[e]) : Elem<T>::lo(cw[e]), si = t ? Elem<T>::hi(sw[e]) : Elem<T>::lo(sw[e]);
+          o1[t] = round_to<T>(round_to<T>(x1 * co) - round_to<T>(x2 * si));
+          o2[t] = round_to<T>(round_to<T>(x2 * co) + round_to<T>(x1 * si));
+        }
+        r1[e] = pack2<T>(o1[0], o1[1]);
+        r2[e] = pack2<T>(o2[0], o2[1]);
+      }
+      qf[kk] = __builtin_bit_cast(vec8, make_uint4(r1[0], r1[1], r1[2], r1[3]));
+      qf[kk + 4] = __builtin_bit_cast(vec8, make_uint4(r2[0], r2[1], r2[2], r2[3]));
+    }
+  }
+
   X32_STAGE_WRITE(0);
   __syncthreads();
 
@@ -800,7 +838,8 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
                             int skip_prefix_mask = 1, void* workspace = nullptr, int64_t total_tokens = 0,
                             int64_t num_splits = 1, const int32_t* page_indptr = nullptr,
                             const int32_t* page_indices = nullptr, int64_t page_size = 1, void* o_fp8 = nullptr,
-                            const float* o_scale = nullptr) {
+                            const float* o_scale = nullptr, const int64_t* q_positions = nullptr,
+                            const void* q_rope_t = nullptr) {
   MI_CHECK_ARG(batch >= 0 && max_extend_len >= 0);
   if (batch == 0 || max_extend_len == 0) return MI_OK;
   MI_CHECK_ARG(q_ext && k_ext && v_ext && (o_ext || o_fp8) && qo_indptr && kv_indptr);
@@ -838,6 +877,8 @@ static int extend_attn_impl(const void* q_ext, const void* k_ext, const void* v_
   p.ws_o = (float*)workspace;
   p.ws_ml = p.ws_o ? p.ws_o + total_tokens * num_q_heads * num_splits * head_dim : nullptr;
   p.o_q = (uint8_t*)o_fp8; p.o_qscale = o_scale;
+  MI_CHECK_ARG((q_positions == nullptr) == (q_rope_t == nullptr) && (!q_rope_t || (o_fp8 && ((uintptr_t)q_rope_t & 15) == 0)));
+  p.q_positions = q_positions; p.q_rope_t = q_rope_t;
   hipStream_t st = (hipStream_t)stream;
   if (o_fp8) {
     // the fp8 output exists in the long-extend kernel only; its caller checked the preconditions (mi_extend_attn_fp8out)
@@ -947,6 +988,9 @@ extern "C" int mi_extend_attn_masked(const void* q_ext, const void* k_ext, const
 // mi_fp8_quant_per_tensor(static, *o_scale) of the T-typed result, bit for bit; o_ext may be null.  The long-extend
 // kernel (head_dim 128, bf16 / fp16 pool, extends >= 64 tokens, no mask / window / cap) writes it from its epilogue;
 // for every other shape the T-typed kernel runs into o_ext (then required) and the quantisation is a second launch.
+// q_positions + cos_sin_cache_t (both or neither; long-extend kernel only, else MI_ERR_UNSUPPORTED): q_ext is UNROTATED
+// and the kernel applies NeoX RoPE to the Q fragments as it loads them (position q_positions[token], cache rounded to T)
+// (the caller rotates only k: mi_rope_neox with num_q_heads = 0); same bits as rotating q with mi_rope_neox first.
 extern "C" int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext /* nullable */,
                                      void* o_fp8, const float* o_scale, const void* k_buf, const void* v_buf,
                                      const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
@@ -955,8 +999,10 @@ extern "C" int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const
                                      int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                                      int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok,
                                      int64_t stride_k_slot, int64_t stride_v_slot, float sm_scale, float logit_cap,
-                                     int causal, int64_t sliding_window, int dtype, void* stream) {
+                                     int causal, int64_t sliding_window, const int64_t* q_positions /* nullable */,
+                                     const void* cos_sin_cache_t /* nullable */, int dtype, void* stream) {
   MI_CHECK_ARG(o_fp8 != nullptr && o_scale != nullptr && total_tokens >= 0);
+  MI_CHECK_ARG((q_positions == nullptr) == (cos_sin_cache_t == nullptr));
   MI_CHECK_ARG((page_indptr == nullptr) == (page_indices == nullptr));
   static const int enable32 = mi_tune("MI_EXTEND_32", 1);
   const bool fused = enable32 && head_dim == 128 && max_extend_len >= 64 && sliding_window <= 0 && !(logit_cap > 0.f) &&
@@ -966,7 +1012,8 @@ extern "C" int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const
                             max_extend_len, num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok,
                             stride_vx_tok, stride_k_slot, stride_v_slot, sm_scale, logit_cap, causal, sliding_window, dtype,
                             stream, false, 1.f, 1.f, nullptr, nullptr, 1, nullptr, 0, 1, page_indptr, page_indices,
-                            page_indptr ? page_size : 1, o_fp8, o_scale);
+                            page_indptr ? page_size : 1, o_fp8, o_scale, q_positions, cos_sin_cache_t);
+  if (q_positions) MI_FAIL(MI_ERR_UNSUPPORTED, "mi_extend_attn_fp8out: Q rotation on load exists in the long-extend kernel only");
   if (!o_ext) MI_FAIL(MI_ERR_INVALID, "mi_extend_attn_fp8out: this shape needs the T-typed output buffer o_ext as well");
   const int rc = extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch,
                                   max_extend_len, num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok,

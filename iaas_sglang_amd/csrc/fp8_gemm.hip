@@ -266,17 +266,6 @@ struct SiluEpi {
   uint8_t* q_out;
   const float* q_scale;
 };
-// EPI == 2 of the tile kernel (qkv projection of a prefill chunk, head_dim 128): NeoX RoPE on the q and k heads and the
-// KV-pool write of the k (rotated) and v rows from the GEMM's epilogue
-struct RopeEpi {
-  const int64_t* positions;     // [M]
-  const float* cos_sin;         // [max_pos][128] = [cos | sin], fp32 (rotary_embedding.py:89-101)
-  void* k_cache;                // [slots][Hkv][128] T
-  void* v_cache;
-  const int64_t* loc;           // [M] pool slot of every row (out_cache_loc)
-  int64_t cache_stride_k, cache_stride_v;   // elements per slot
-  int32_t num_q_heads, num_kv_heads;
-};
 
 // Epilogue of the decode-shaped kernel (a function so that kernel variants can share it): every wave is past
 // the last phase barrier when it is called, so LDS may be reused (EPI == 1 exchange buffer).
@@ -1340,8 +1329,7 @@ __device__ __forceinline__ void stream_store16(void* dst, uint4 v) {
 template <typename OutT, int EPI = 0>
 __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, int mblocks, int nblocks,
                                                             float* __restrict__ slab, int S,
-                                                            const SiluEpi epi = SiluEpi{nullptr, nullptr},
-                                                            const RopeEpi rope = RopeEpi{}) {
+                                                            const SiluEpi epi = SiluEpi{nullptr, nullptr}) {
   constexpr int BM = 256, BN = 256, BK = 128;
   constexpr int TILE = BM * BK;            // 32 KiB per operand per stage
   // SPLIT ring over all 160 KiB of LDS: two activation stages (requested one k-step ahead) at [0, 64 KiB), THREE weight
@@ -1411,8 +1399,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     const int gsz = min(mblocks - first_m, GM);
     const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
     t.m0 = (int64_t)mb * BM;
-    t.n0 = (int64_t)nb * (EPI == 1 ? BN / 2 : BN);
-    const int64_t w0 = EPI == 1 ? (wave < 4 ? t.n0 : Ihalf + t.n0 - 128) : t.n0;     // EPI 1: waves 4..7 stage the UP rows
+    t.n0 = (int64_t)nb * (EPI ? BN / 2 : BN);
+    const int64_t w0 = EPI ? (wave < 4 ? t.n0 : Ihalf + t.n0 - 128) : t.n0;     // EPI: waves 4..7 stage the UP rows
     t.xblk = uniform_ptr(p.a + t.m0 * p.lda);
     t.wblk = uniform_ptr(p.b + w0 * p.ldb);
     t.xclamp = __builtin_amdgcn_readfirstlane((int)min((int64_t)255, p.M - 1 - t.m0));
@@ -1460,7 +1448,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       pf_base = cur.xblk;
       pf_off = (uint32_t)((min(m0 + r, p.M - 1) - m0) * p.lda);
     } else {
-      const int64_t pw0 = EPI == 1 ? (r < 128 ? n0 : Ihalf + n0 - 128) : n0;   // uniform per wave (64-row groups)
+      const int64_t pw0 = EPI ? (r < 128 ? n0 : Ihalf + n0 - 128) : n0;   // uniform per wave (64-row groups)
       pf_base = p.b + pw0 * p.ldb;
       pf_off = (uint32_t)((min(pw0 + r, p.N - 1) - pw0) * p.ldb);
     }
@@ -1638,83 +1626,6 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (nbase + r < p.N) o[r] = acc[i][j][r];
-        }
-      }
-    }
-  } else if constexpr (EPI == 2) {
-    // qkv projection with RoPE + KV-pool write (host: N % 256 == 0, head_dim 128, per-tensor scales, no bias, S == 1).
-    // The tile's 256 columns are two heads; waves (wm, 2c) and (wm, 2c + 1) hold dims 0..63 and 64..127 of head c for
-    // the same 128 rows.  Each wave stages its T-rounded GEMM outputs exactly as the plain epilogue does (that IS the
-    // unfused GEMM's output), and on the way out every lane pairs its 16-byte chunk with the partner wave's chunk of the
-    // same (row, column) -- the (x1, x2) of 8 rotation pairs -- and applies rope_neox_kernel's arithmetic (cos / sin
-    // rounded to T, every product and sum rounded to T): bit-identical to GEMM -> mi_rope_neox -> mi_kv_write, without
-    // the rope kernel's read + write of q and k (671 MB per 32 k tokens) and the scatter kernel's read of k and v.
-    // q / k / v rows go to `out` (extend attention reads the NEW tokens' K and V from there), k / v rows also to the pool.
-    char* const region = wave < 4 ? free_x : free_w;
-    char* stg = region + (wave & 3) * 8192;
-    const char* pst = region + ((wave ^ 1) & 3) * 8192;
-    const int pr = lane >> 3, pc = lane & 7;
-    const int head = (int)(n0 >> 7) + (wn >> 1);
-    const bool rot = head < rope.num_q_heads + rope.num_kv_heads;
-    const bool second = (wn & 1) != 0;                        // this wave holds x2 (dims 64..127) of its head
-    const int kvh = head - rope.num_q_heads;                  // >= 0: k head kvh, or v head kvh - Hkv
-    OutT* cache = nullptr;
-    int64_t cstride = 0;
-    if (kvh >= 0) {
-      const bool isk = kvh < rope.num_kv_heads;
-      cache = (OutT*)(isk ? rope.k_cache : rope.v_cache) + (int64_t)(isk ? kvh : kvh - rope.num_kv_heads) * 128 + (wn & 1) * 64 + pc * 8;
-      cstride = isk ? rope.cache_stride_k : rope.cache_stride_v;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h) __syncthreads();            // the partner has read round 0 out of this wave's staging area
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 2 * j + (q >> 1);
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int i = h * 4 + ii, row = ii * 16 + r16;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sa0 * sb0 + 0.f;
-          *(uint2*)(stg + row * 128 + ((c ^ (row & 7)) << 4) + (q & 1) * 8) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 8 + pr;
-        uint4 v = *(const uint4*)(stg + row * 128 + ((pc ^ (row & 7)) << 4));
-        const int64_t m = m0 + wm * 128 + h * 64 + row;
-        const int64_t mc = min(m, p.M - 1);
-        if (rot) {
-          const uint4 w = *(const uint4*)(pst + row * 128 + ((pc ^ (row & 7)) << 4));
-          const float* cs = rope.cos_sin + rope.positions[mc] * 128 + pc * 8;
-          const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4);
-          const f32x4 s0 = *(const f32x4*)(cs + 64), s1 = *(const f32x4*)(cs + 68);
-          const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-          const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-          const uint32_t ow[4] = {v.x, v.y, v.z, v.w}, pw[4] = {w.x, w.y, w.z, w.w};
-          uint32_t res[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float o2[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const float own = t ? Elem<OutT>::hi(ow[e]) : Elem<OutT>::lo(ow[e]);
-              const float par = t ? Elem<OutT>::hi(pw[e]) : Elem<OutT>::lo(pw[e]);
-              const float co = round_to<OutT>(cv[2 * e + t]), si = round_to<OutT>(sv[2 * e + t]);
-              // first half: o1 = x1 cos - x2 sin (own = x1); second half: o2 = x2 cos + x1 sin (own = x2)
-              const float a = round_to<OutT>(own * co), b = round_to<OutT>(par * si);
-              o2[t] = second ? round_to<OutT>(a + b) : round_to<OutT>(a - b);
-            }
-            res[e] = pack2<OutT>(o2[0], o2[1]);
-          }
-          v = make_uint4(res[0], res[1], res[2], res[3]);
-        }
-        if (m < p.M) {
-          stream_store16((OutT*)p.out + m * p.ldo + n0 + wn * 64 + pc * 8, v);
-          if (cache) stream_store16(cache + rope.loc[m] * cstride, v);
         }
       }
     }
@@ -2021,48 +1932,6 @@ MI_INTERNAL int mi_fp8_gemm_silu_epilogue(const void* a, const void* b_nk, const
   }
 #undef LAUNCH_EPI
 #undef LAUNCH_EPI_LEGACY
-  MI_CHECK_LAUNCH();
-  return MI_OK;
-}
-
-// Prefill form of mi_fp8_gemm_rope_kvwrite: the qkv projection of a chunk of M > 512 tokens on the 256 x 256 tile kernel
-// with RoPE and the KV-pool write in its epilogue (fp8_gemm_tile_kernel<EPI = 2>).  qkv_out [M, (Hq + 2 Hkv) * 128] (row
-// pitch ldo) receives q and k ROTATED and v -- what mi_fp8_gemm + mi_rope_neox leave there -- and the pool rows at loc[m]
-// receive k (rotated) and v -- what mi_kv_write would store: bit-identical to the three separate calls.  Per-tensor
-// scales, no bias, head_dim 128.  MI_ERR_UNSUPPORTED for shapes the tile kernel would split over K (a few hundred
-// tokens: the caller keeps the unfused sequence there).
-extern "C" int mi_fp8_gemm_qkv_rope_kvwrite(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
-                                            const int64_t* positions, const float* cos_sin_cache, void* qkv_out,
-                                            void* k_cache, void* v_cache, const int64_t* loc, int64_t M,
-                                            int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t K,
-                                            int64_t lda, int64_t ldb, int64_t ldo, int64_t cache_stride_k,
-                                            int64_t cache_stride_v, int dtype, void* stream) {
-  MI_CHECK_ARG(M >= 0 && K > 0 && num_q_heads > 0 && num_kv_heads > 0);
-  if (M == 0) return MI_OK;
-  MI_CHECK_ARG(a && b_nk && scale_a && scale_b && positions && cos_sin_cache && qkv_out && k_cache && v_cache && loc);
-  MI_CHECK_ARG(dtype == MI_BF16 || dtype == MI_FP16);
-  const int64_t N = (num_q_heads + 2 * num_kv_heads) * head_dim;
-  if (head_dim != 128 || N % 256 != 0 || M <= 512 || K % 128 != 0)
-    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_qkv_rope_kvwrite: head_dim 128, an even head count, M > 512, K %% 128 == 0");
-  if (tile_splits(M, N, K) != 1)
-    MI_FAIL(MI_ERR_UNSUPPORTED, "mi_fp8_gemm_qkv_rope_kvwrite: M = %lld runs split-K on the tile kernel (unfused sequence)", (long long)M);
-  MI_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && lda < (1 << 24) && ldb < (1 << 24) && ldo % 8 == 0 && ldo >= N);
-  MI_CHECK_ARG(cache_stride_k % 8 == 0 && cache_stride_v % 8 == 0 && cache_stride_k >= num_kv_heads * 128 && cache_stride_v >= num_kv_heads * 128);
-  MI_CHECK_ARG(!(((uintptr_t)a | (uintptr_t)b_nk | (uintptr_t)qkv_out | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)cos_sin_cache) & 15));
-  GemmParams p;
-  p.a = (const uint8_t*)a; p.b = (const uint8_t*)b_nk; p.sa = scale_a; p.sb = scale_b; p.bias = nullptr; p.out = qkv_out;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldo = ldo; p.sa_row = 0; p.sb_row = 0; p.rotate = gemm_rotate(); p.var = xd_var(); p.rot_step = xw_rot();
-  RopeEpi rope;
-  rope.positions = positions; rope.cos_sin = cos_sin_cache; rope.k_cache = k_cache; rope.v_cache = v_cache; rope.loc = loc;
-  rope.cache_stride_k = cache_stride_k; rope.cache_stride_v = cache_stride_v;
-  rope.num_q_heads = (int32_t)num_q_heads; rope.num_kv_heads = (int32_t)num_kv_heads;
-  const int mblocks = (int)cdiv64(M, 256), nblocks = (int)(N / 256);
-  hipStream_t st = (hipStream_t)stream;
-  const SiluEpi none{nullptr, nullptr};
-  if (dtype == MI_BF16)
-    fp8_gemm_tile_kernel<bf16_t, 2><<<(unsigned)tile_grid(mblocks * nblocks), 512, 5 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, none, rope);
-  else
-    fp8_gemm_tile_kernel<f16_t, 2><<<(unsigned)tile_grid(mblocks * nblocks), 512, 5 * 256 * 128, st>>>(p, mblocks, nblocks, nullptr, 1, none, rope);
   MI_CHECK_LAUNCH();
   return MI_OK;
 }

@@ -186,6 +186,9 @@ class LlamaStack:
         self.lm_head = dummy(self.vocab_shard, s.hidden)           # bf16, unquantised (logits_processor.py:423-480)
         self.embed = dummy(s.vocab, s.hidden)                       # token ids -> hidden (plumbing, replicated)
         self.cos_sin = rope_cache(D, s.context_len, s.rope_theta, device)
+        # the cache as RotaryEmbedding.forward_native uses it (cast to the activation dtype per call,
+        # rotary_embedding.py:150-151): the fused prefill forms read this copy
+        self.cos_sin_t = self.cos_sin.to(dtype).contiguous()
 
     @staticmethod
     def _init_linear(lin, dummy):
@@ -408,34 +411,33 @@ class LlamaStack:
             if first:
                 residual = hidden
             qs = L.qkv.fused_quant_scale()
-            kv_saved = False
             if qs is not None:
-                qx = ops.rmsnorm_fp8(hidden, L.input_norm, s.rms_eps, qs, residual=None if first else residual)
-                qkv = None
-                fuse = getattr(L.qkv.quant_method, "apply_qkv_rope_kvwrite", None)
-                pool = fb.token_to_kv_pool
-                if (fuse is not None and LlamaStack.fuse_decode_layer and fb.forward_mode.is_extend()
-                        and pool.get_key_buffer(L.attn.layer_id).dtype == self.dtype):
-                    # prefill: RoPE and the KV-pool write ride in the qkv GEMM's epilogue (None: no fused form here)
-                    qkv = fuse(L.qkv, qx, positions, self.cos_sin, pool.get_key_buffer(L.attn.layer_id),
-                               pool.get_value_buffer(L.attn.layer_id), fb.out_cache_loc, self.Hq, self.Hkv, s.head_dim)
-                    kv_saved = qkv is not None
-                if qkv is None:
-                    qkv = L.qkv.forward_prequantized(qx, self.dtype)
+                qkv = L.qkv.forward_prequantized(
+                    ops.rmsnorm_fp8(hidden, L.input_norm, s.rms_eps, qs, residual=None if first else residual),
+                    self.dtype)
             else:
                 x = ops.rmsnorm(hidden, L.input_norm, s.rms_eps, residual=None if first else residual)
                 qkv = L.qkv(x)
             q, k, v = qkv[:, : self.q_size], qkv[:, self.q_size: self.q_size + self.kv_size], qkv[:, self.q_size + self.kv_size:]
-            if not kv_saved:
-                ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
             qs_o = L.o.fused_quant_scale()
+            # prefill: where this batch's attention kernel can rotate Q as it loads it (long extends, fp8 o_proj input),
+            # only k goes through the rope kernel -- its read + write of q (4/5 of its traffic) disappears
+            q_rope = None
+            if (qs_o is not None and LlamaStack.fuse_decode_layer and not fb.forward_mode.is_decode()
+                    and fb.token_to_kv_pool.get_key_buffer(L.attn.layer_id).dtype == self.dtype
+                    and getattr(backend, "extend_rotates_q", lambda *_: False)(L.attn, qs_o)):
+                ops.rope_neox_k_(k, positions, self.cos_sin, s.head_dim)
+                q_rope = (positions, self.cos_sin_t)
+            else:
+                ops.rope_neox_(q, k, positions, self.cos_sin, s.head_dim)
             if qs_o is not None:     # attention hands o_proj its fp8 input (decode: the split merge; extend: the epilogue)
                 a8 = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
-                                     L.attn, fb, save_kv_cache=not kv_saved, fp8_out_scale=qs_o)
+                                     L.attn, fb, fp8_out_scale=qs_o,
+                                     **({"q_rope": q_rope} if q_rope is not None else {}))
                 hidden = self._all_reduce(L.o.forward_prequantized(a8, self.dtype))
             else:
                 a = backend.forward(q, k.reshape(-1, self.Hkv, s.head_dim), v.reshape(-1, self.Hkv, s.head_dim),
-                                    L.attn, fb, save_kv_cache=not kv_saved)
+                                    L.attn, fb)
                 hidden = self._all_reduce(L.o(a))
             qs = L.gate_up.fused_quant_scale()
             qs_down = L.down.fused_quant_scale()

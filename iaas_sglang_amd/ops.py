@@ -309,11 +309,15 @@ def extend_attention_fp8out(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.T
                             kv_indptr_t: torch.Tensor, kv_indices_t: torch.Tensor, max_extend_len: int, sm_scale: float,
                             logit_cap: float = 0.0, causal: bool = True, sliding_window: int = -1,
                             page_indptr: Optional[torch.Tensor] = None, page_indices: Optional[torch.Tensor] = None,
-                            page_size: int = 1, o: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            page_size: int = 1, o: Optional[torch.Tensor] = None,
+                            q_positions: Optional[torch.Tensor] = None,
+                            cos_sin_cache_t: Optional[torch.Tensor] = None) -> torch.Tensor:
     """extend_attention (token- or page-granular prefix) returning the output quantised for the following FP8 linear:
     o_fp8 [E, Hq * D] e4m3fn = fp8_quant_per_tensor(static, o_scale) of the T-typed result, bit for bit.  `o`
     (optional [E, Hq, D]) also receives the T-typed result; it is REQUIRED for the shapes the long-extend kernel does
-    not take (fp8_out_is_fused says which), where the quantisation is a second launch."""
+    not take (extend_fp8_out_is_fused says which), where the quantisation is a second launch.  q_positions [E] int64 +
+    cos_sin_cache_t (rotary cache cast to q.dtype): q is UNROTATED and the kernel applies NeoX RoPE to Q as it loads it
+    (fused shapes only); the caller rotates only k (rope_neox_k_)."""
     E, Hq, D = q.shape
     Hkv = k_ext.shape[1]
     B = qo_indptr.shape[0] - 1
@@ -324,13 +328,18 @@ def extend_attention_fp8out(q: torch.Tensor, k_ext: torch.Tensor, v_ext: torch.T
     for t in (qo_indptr, kv_indptr_t, kv_indices_t):
         assert t.dtype == torch.int32
     assert (page_indptr is None) == (page_indices is None)
+    assert (q_positions is None) == (cos_sin_cache_t is None)
+    if q_positions is not None:
+        assert q_positions.dtype == torch.int64 and q_positions.numel() == E
+        assert cos_sin_cache_t.dtype == q.dtype and cos_sin_cache_t.shape[1] == D and cos_sin_cache_t.is_contiguous()
     check(lib.mi_extend_attn_fp8out(_ptr(q), _ptr(k_ext), _ptr(v_ext), _ptr(o) if o is not None else None, _ptr(o_fp8),
                                     _ptr(o_scale), _ptr(k_buf), _ptr(v_buf), _ptr(qo_indptr), _ptr(kv_indptr_t),
                                     _ptr(kv_indices_t), _ptr(page_indptr) if page_indptr is not None else None,
                                     _ptr(page_indices) if page_indices is not None else None, int(page_size), B, E,
                                     int(max_extend_len), Hq, Hkv, D, q.stride(0), o.stride(0) if o is not None else Hq * D,
                                     k_ext.stride(0), v_ext.stride(0), k_buf.stride(0), v_buf.stride(0), float(sm_scale),
-                                    float(logit_cap), int(causal), int(sliding_window), _dt(q), _stream()),
+                                    float(logit_cap), int(causal), int(sliding_window), _ptr(q_positions),
+                                    _ptr(cos_sin_cache_t), _dt(q), _stream()),
           "mi_extend_attn_fp8out")
     return o_fp8
 
@@ -617,6 +626,15 @@ def rope_neox_(q: torch.Tensor, k: torch.Tensor, positions: torch.Tensor, cos_si
           "mi_rope_neox")
 
 
+def rope_neox_k_(k: torch.Tensor, positions: torch.Tensor, cos_sin_cache: torch.Tensor, head_dim: int) -> None:
+    """In-place NeoX RoPE on k [T, Hkv*D] only (mi_rope_neox with no q heads): for batches whose attention kernel
+    rotates Q as it loads it (extend_attention_fp8out(q_positions=...))."""
+    assert k.stride(-1) == 1 and positions.dtype == torch.int64
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim
+    check(lib.mi_rope_neox(_ptr(k), _ptr(k), _ptr(positions), _ptr(cos_sin_cache), k.shape[0], 0, k.shape[1] // head_dim,
+                           head_dim, k.stride(0), k.stride(0), _dt(k), _stream()), "mi_rope_neox")
+
+
 def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1
     M, I2 = x.shape
@@ -762,35 +780,6 @@ def fp8_gemm_rope_kvwrite(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Te
                                        k_cache.stride(0), v_cache.stride(0), _dt(k_cache), _ptr(ws), nbytes, _stream()),
           "mi_fp8_gemm_rope_kvwrite")
     return q
-
-
-def fp8_gemm_qkv_rope_kvwrite(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
-                              positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
-                              v_cache: torch.Tensor, loc: torch.Tensor, num_q_heads: int, num_kv_heads: int,
-                              head_dim: int) -> Optional[torch.Tensor]:
-    """Prefill form of fp8_gemm_rope_kvwrite: qkv linear of an EXTEND chunk with NeoX RoPE and the KV-pool write in the
-    tile GEMM's epilogue.  Returns qkv [M, (Hq + 2 Hkv) * D] (q, k rotated; v) -- the same bits as fp8_gemm + rope_neox_
-    + kv_write -- or None where no fused form exists (M <= 512, head_dim != 128, or a token count the tile kernel
-    splits over K): the caller then runs the three calls."""
-    _check_fp8_operands(a, b_kn, scale_a, scale_b)
-    M, K = a.shape
-    N = b_kn.shape[1]
-    assert N == (num_q_heads + 2 * num_kv_heads) * head_dim
-    if M <= 512 or head_dim != 128 or N % 256 != 0 or K % 128 != 0 or scale_a.numel() != 1 or scale_b.numel() != 1:
-        return None
-    assert positions.dtype == torch.int64 and loc.dtype == torch.int64 and positions.numel() == M and loc.numel() == M
-    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim and cos_sin_cache.is_contiguous()
-    assert k_cache.dtype == v_cache.dtype and k_cache[0].is_contiguous() and v_cache[0].is_contiguous()
-    assert k_cache[0].numel() == num_kv_heads * head_dim and v_cache[0].numel() == num_kv_heads * head_dim
-    qkv = torch.empty(M, N, dtype=k_cache.dtype, device=a.device)
-    rc = lib.mi_fp8_gemm_qkv_rope_kvwrite(_ptr(a), _ptr(b_kn), _ptr(scale_a), _ptr(scale_b), _ptr(positions),
-                                          _ptr(cos_sin_cache), _ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(loc), M,
-                                          num_q_heads, num_kv_heads, head_dim, K, a.stride(0), b_kn.stride(1),
-                                          qkv.stride(0), k_cache.stride(0), v_cache.stride(0), _dt(k_cache), _stream())
-    if rc == -2:          # MI_ERR_UNSUPPORTED: this token count runs split-K on the tile kernel
-        return None
-    check(rc, "mi_fp8_gemm_qkv_rope_kvwrite")
-    return qkv
 
 
 def fp8_gemm_silu_mul(a: torch.Tensor, b_kn: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,

@@ -136,16 +136,6 @@ class Fp8FusedDecodeMixin:
                                          positions, cos_sin_cache, k_cache, v_cache, loc, num_q_heads, num_kv_heads,
                                          head_dim)
 
-    def apply_qkv_rope_kvwrite(self, layer, qx, positions, cos_sin_cache, k_cache, v_cache, loc, num_q_heads,
-                               num_kv_heads, head_dim):
-        """Prefill: qkv = linear(qx) with q and k rotated, k / v rows also stored in the KV pool at `loc` -- from the
-        tile GEMM's epilogue.  None when the shape has no fused form (the caller runs linear, rope, kv-write)."""
-        if layer.weight_scale.numel() != 1 or getattr(layer, "bias", None) is not None:
-            return None
-        return ops.fp8_gemm_qkv_rope_kvwrite(qx, layer.weight, layer.input_scale.reshape(1),
-                                             layer.weight_scale.reshape(1), positions, cos_sin_cache, k_cache, v_cache,
-                                             loc, num_q_heads, num_kv_heads, head_dim)
-
     def apply_silu_mul(self, layer, qx, next_scale, act_dtype):
         """fp8(silu(gate) * up) of linear(qx) = [gate | up], quantised with next_scale."""
         return ops.fp8_gemm_silu_mul(qx, layer.weight, layer.input_scale.reshape(1), layer.weight_scale.reshape(1),

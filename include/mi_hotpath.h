@@ -227,6 +227,9 @@ int mi_extend_attn_paged(const void* q_ext, const void* k_ext, const void* v_ext
  * bf16 / fp16 pool, max_extend_len >= 64, no window / cap) writes it from its epilogue; every other shape runs the
  * T-typed kernel into o_ext (then required: MI_ERR_INVALID without it) and quantises in a second launch.  page_indptr /
  * page_indices: both null (token-granular prefix) or both given (as mi_extend_attn_paged).
+ * q_positions [total_tokens] + cos_sin_cache_t (the rotary cache [max_pos][128] rounded to T; both or neither, long-extend
+ * kernel only, MI_ERR_UNSUPPORTED otherwise): q_ext is UNROTATED and NeoX RoPE is applied to Q as it is loaded (the
+ * caller then rotates only k: mi_rope_neox with num_q_heads = 0); same bits as mi_rope_neox on q first.
  * replaces: extend_attention_fwd (extend_attention.py:306-438) followed by static_quant_fp8 in apply_fp8_linear
  * (fp8_utils.py:654-660) of the o_proj RowParallelLinear (models/llama.py:186-190). */
 int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const void* v_ext, void* o_ext /* nullable */,
@@ -237,6 +240,7 @@ int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const void* v_ex
                           int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t stride_q_tok,
                           int64_t stride_o_tok, int64_t stride_kx_tok, int64_t stride_vx_tok, int64_t stride_k_slot,
                           int64_t stride_v_slot, float sm_scale, float logit_cap, int causal, int64_t sliding_window,
+                          const int64_t* q_positions /* nullable */, const void* cos_sin_cache_t /* nullable */,
                           int dtype, void* stream);
 
 /* mi_extend_attn whose cached PREFIX lives in an fp8 (e4m3fn) pool: k_buf8/v_buf8 hold bytes, stride_*_slot in
@@ -480,20 +484,6 @@ int mi_fp8_gemm_rope_kvwrite(const void* a, const void* b_nk, const float* scale
                              int64_t head_dim, int64_t K, int64_t lda, int64_t ldb, int64_t ldq,
                              int64_t cache_stride_k, int64_t cache_stride_v, int dtype,
                              void* workspace, int64_t workspace_bytes, void* stream);
-
-/* Prefill form of mi_fp8_gemm_rope_kvwrite (M > 512 tokens, head_dim 128): the qkv projection on the 256 x 256 tile
- * kernel with NeoX RoPE and the KV-pool write in its epilogue.  qkv_out [M, (Hq + 2*Hkv)*128] (row pitch ldo) = q and k
- * ROTATED and v (extend attention reads the new tokens' K / V from there); k_cache / v_cache rows loc[m] = k (rotated) /
- * v.  Bit-identical to mi_fp8_gemm + mi_rope_neox + mi_kv_write.  MI_ERR_UNSUPPORTED where the tile kernel would split
- * over K (a few hundred tokens): keep the three calls there.
- * replaces: apply_fp8_linear (fp8_utils.py:715-723) + RotaryEmbedding.forward_native (rotary_embedding.py:49-166) +
- * MHATokenToKVPool.set_kv_buffer (memory_pool.py:454-455) of an EXTEND batch. */
-int mi_fp8_gemm_qkv_rope_kvwrite(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
-                                 const int64_t* positions, const float* cos_sin_cache, void* qkv_out,
-                                 void* k_cache, void* v_cache, const int64_t* loc, int64_t M,
-                                 int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t K,
-                                 int64_t lda, int64_t ldb, int64_t ldo, int64_t cache_stride_k,
-                                 int64_t cache_stride_v, int dtype, void* stream);
 
 /* gate_up = a.b_nk with N = 2*I; q_out [M, I] = fp8(round_T(silu(gate) * up) / *q_scale).  When the GEMM
  * needs no split-K (N large enough to fill the chip) the activation runs in the GEMM's own epilogue and

@@ -1037,3 +1037,37 @@ def test_extend_fp8_output_is_bit_identical_to_extend_then_static_quant(dtype, p
         assert torch.equal(o8.view(torch.uint8), ref8.view(torch.uint8))
         if o is not None:
             assert torch.equal(o.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("pre,ext,paged", [([0] * 2, [1500, 200], False), ([1024, 17, 0], [256, 1000, 65], True)])
+def test_extend_q_rotation_on_load_is_bit_identical_to_rope_then_extend(dtype, pre, ext, paged):
+    """mi_extend_attn_fp8out with q_positions + the T-typed rotary cache (Q rotated in registers as the long-extend kernel
+    loads it; the partner of the qkv GEMM epilogue's rotate_q = 0) against mi_rope_neox on q followed by the same call
+    without them: the same fp8 bytes and the same T-typed output."""
+    from iaas_sglang_amd import harness as H, ops
+    page_size = 16
+    g = torch.Generator().manual_seed(23 + len(pre))
+    q, kn, vn, kc, vc, qop, kvp, idx, pi, px = _paged_prefix_case(g, pre, ext, page_size)
+    q, kn, vn, kc, vc = (t.to(dtype) for t in (q, kn, vn, kc, vc))
+    E, Hq, D = q.shape
+    cache = H.rope_cache(D, 4096, 10000.0, DEV)
+    cache_t = cache.to(dtype)
+    pos = torch.cat([torch.arange(p, p + e) for p, e in zip(pre, ext)]).to(DEV)
+    pos[3] = 4000                                    # positions are READ, not derived from the prefix length
+    scale = torch.tensor([0.0123], dtype=torch.float32, device=DEV)
+    pargs = dict(page_indptr=pi, page_indices=px, page_size=page_size) if paged else {}
+    q_rot = q.clone()
+    k_dummy = kn.clone()
+    ops.rope_neox_(q_rot.view(E, Hq * D), k_dummy.view(E, -1), pos, cache, D)
+    ref8 = torch.empty(E, Hq * D, dtype=ops.FP8_DTYPE, device=DEV)
+    ref = torch.empty_like(q)
+    ops.extend_attention_fp8out(q_rot, kn, vn, ref8, scale, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1, o=ref, **pargs)
+    o8 = torch.full((E, Hq * D), 0x7f, dtype=torch.uint8, device=DEV).view(ops.FP8_DTYPE)
+    o = torch.empty_like(q)
+    ops.extend_attention_fp8out(q, kn, vn, o8, scale, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1, o=o,
+                                q_positions=pos, cos_sin_cache_t=cache_t, **pargs)
+    torch.cuda.synchronize()
+    assert torch.equal(o8.view(torch.uint8), ref8.view(torch.uint8))
+    assert torch.equal(o.view(torch.int16), ref.view(torch.int16))
+    assert not torch.equal(q.view(torch.int16), q_rot.view(torch.int16))
