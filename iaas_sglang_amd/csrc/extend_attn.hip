@@ -466,16 +466,30 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   const int pshift = p.page_shift;
   const int32_t pg_base = pshift ? p.page_indptr[req] : 0;
 
-  // ---- staging: thread -> 16-byte chunk (tid & 15) of key rows (tid >> 4) and 32 + (tid >> 4) of the tile
-  const int srow = tid >> 4, sch = tid & 15;
-  auto lds_off = [](int row, int ch) __attribute__((always_inline)) -> int {
-    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-  };
-  // named registers + macros: register ARRAYS captured by a lambda end up in scratch
-  uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+  // ---- staging by LDS-DMA (round 3; was: 8 register loads + 8 ds_write_b128 per thread and tile, 32 VGPRs of a kernel
+  // that sits at the 256-VGPR cap).  Wave w fills rows RP * ps + 4 w .. + 3 of both tiles with ONE 1-KiB piece per
+  // pass ps: lane L = (row 4 w + (L >> 4), 16-byte POSITION L & 15); the LDS image keeps chunk c of row r at position
+  // c ^ x(r), so the lane fetches chunk (L & 15) ^ x(r) -- the swizzle moves to the source side, and x(r) depends on the
+  // low four bits of r only (RP * ps is a multiple of 32): one constant per thread.
+  //   fast form: a tile that lies wholly in the NEW tokens (no index, no clamp: every tile of a prompt without cached
+  //   prefix except the last) is a scalar base + four constant 32-bit lane offsets -- no vector address arithmetic at
+  //   all (the per-load min / compare / 64-bit multiply-add of the general form was ~120 VALU per thread and tile in a
+  //   kernel whose softmax VALU, not its MFMA, is the bound);
+  //   general form: per-lane 64-bit addresses as before (prefix rows through kv_indices / page_indices, the clamped
+  //   last tile).
+  // The caller of a stage waits `vmcnt(0)` and meets the workgroup barrier before anybody reads it.
+  const int srow = tid >> 4, spos = tid & 15;
+  const int sch = spos ^ (((srow & 3) << 2) | ((srow >> 2) & 3));      // the chunk of its row this lane fetches
   const bool same_strides = p.stride_k_slot == p.stride_v_slot && p.stride_kx_tok == p.stride_vx_tok;   // the usual case
   const int64_t hd_off = (int64_t)hk * D + sch * 8;
-#define X32_LOAD_ONE(tile_, ps_, KR, VR)                                                                            \
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (uint32_t)wave * 1024u);
+  uint32_t xoffk[4], xoffv[4];          // byte offsets of this lane's four rows from the tile's first new-token row
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    xoffk[ps] = (uint32_t)(((int64_t)(RP * ps + srow) * p.stride_kx_tok + hd_off) * (int64_t)sizeof(T));
+    xoffv[ps] = (uint32_t)(((int64_t)(RP * ps + srow) * p.stride_vx_tok + hd_off) * (int64_t)sizeof(T));
+  }
+#define X32_DMA_ONE(tile_, st_, ps_)                                                                                \
   {                                                                                                                 \
     const int32_t kp_ = min((tile_) * KT + RP * (ps_) + srow, n_keys - 1);                                          \
     const bool in_pool_ = kp_ < prefix;                                                                             \
@@ -484,29 +498,29 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     const int64_t t_ = q_start + max(kp_ - prefix, 0);                                                              \
     const int64_t ko_ = (in_pool_ ? slot_ * p.stride_k_slot : t_ * p.stride_kx_tok) + hd_off;                       \
     const int64_t vo_ = same_strides ? ko_ : (in_pool_ ? slot_ * p.stride_v_slot : t_ * p.stride_vx_tok) + hd_off;  \
-    KR = *(const uint4*)((in_pool_ ? (const T*)p.k_buf : (const T*)p.k_ext) + ko_);                                 \
-    VR = *(const uint4*)((in_pool_ ? (const T*)p.v_buf : (const T*)p.v_ext) + vo_);                                 \
+    glds16((in_pool_ ? (const T*)p.k_buf : (const T*)p.k_ext) + ko_,                                                \
+           lds_piece + (uint32_t)((st_) * STAGE + (ps_) * RP * ROWB));                                              \
+    glds16((in_pool_ ? (const T*)p.v_buf : (const T*)p.v_ext) + vo_,                                                \
+           lds_piece + (uint32_t)((st_) * STAGE + TILE + (ps_) * RP * ROWB));                                       \
   }
-#define X32_STAGE_LOAD(tile_)                       \
-  {                                                 \
-    X32_LOAD_ONE(tile_, 0, kreg0, vreg0);           \
-    X32_LOAD_ONE(tile_, 1, kreg1, vreg1);           \
-    X32_LOAD_ONE(tile_, 2, kreg2, vreg2);           \
-    X32_LOAD_ONE(tile_, 3, kreg3, vreg3);           \
+#define X32_STAGE_DMA(tile_, st_)                                                                                   \
+  {                                                                                                                 \
+    const int32_t t0_ = (tile_) * KT;                                                                               \
+    if (t0_ >= prefix && t0_ + KT <= n_keys) {        /* wave-uniform: scalars only */                              \
+      const uint8_t* kb_ = uniform_ptr((const T*)p.k_ext + (int64_t)(q_start + t0_ - prefix) * p.stride_kx_tok);     \
+      const uint8_t* vb_ = uniform_ptr((const T*)p.v_ext + (int64_t)(q_start + t0_ - prefix) * p.stride_vx_tok);     \
+      _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                            \
+        glds16_s(xoffk[ps], kb_, lds_piece + (uint32_t)((st_) * STAGE + ps * RP * ROWB));                           \
+        glds16_s(xoffv[ps], vb_, lds_piece + (uint32_t)((st_) * STAGE + TILE + ps * RP * ROWB));                    \
+      }                                                                                                             \
+    } else {                                                                                                        \
+      X32_DMA_ONE(tile_, st_, 0);                                                                                   \
+      X32_DMA_ONE(tile_, st_, 1);                                                                                   \
+      X32_DMA_ONE(tile_, st_, 2);                                                                                   \
+      X32_DMA_ONE(tile_, st_, 3);                                                                                   \
+    }                                                                                                               \
   }
-#define X32_STAGE_WRITE(st_)                                            \
-  {                                                                     \
-    const int o0_ = lds_off(srow, sch), o1_ = lds_off(RP + srow, sch);  \
-    const int o2_ = lds_off(2 * RP + srow, sch), o3_ = lds_off(3 * RP + srow, sch); \
-    *(uint4*)(smem + (st_) * STAGE + o0_) = kreg0;                      \
-    *(uint4*)(smem + (st_) * STAGE + TILE + o0_) = vreg0;               \
-    *(uint4*)(smem + (st_) * STAGE + o1_) = kreg1;                      \
-    *(uint4*)(smem + (st_) * STAGE + TILE + o1_) = vreg1;               \
-    *(uint4*)(smem + (st_) * STAGE + o2_) = kreg2;                      \
-    *(uint4*)(smem + (st_) * STAGE + TILE + o2_) = vreg2;               \
-    *(uint4*)(smem + (st_) * STAGE + o3_) = kreg3;                      \
-    *(uint4*)(smem + (st_) * STAGE + TILE + o3_) = vreg3;               \
-  }
+#define X32_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   f32x16 acc[4];
 #pragma unroll
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     vhi[db] = (uint32_t)(256 * (4 * h + tq + 8) + 16 * ((4 * db + tcol) ^ ((tq << 2) | (h + 2))) + 8 * (tp & 1));
   }
 
-  X32_STAGE_LOAD(0);
+  X32_STAGE_DMA(0, 0);
   // (Q rotation sits here so that its position -> cos / sin round trips run under the first K / V tile's loads; in front
   // of them it added ~3 us of exposed latency to every work item: 16 x 2048 causal 0.78 -> 0.86 ms)
   if (p.q_rope_t) {
@@ -564,13 +578,13 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     }
   }
 
-  X32_STAGE_WRITE(0);
+  X32_STAGE_WAIT();
   __syncthreads();
 
   for (int32_t tile = 0; tile < n_tiles; ++tile) {
     const int st = tile & 1;
     const bool has_next = tile + 1 < n_tiles;
-    if (has_next) X32_STAGE_LOAD(tile + 1);
+    if (has_next) X32_STAGE_DMA(tile + 1, st ^ 1);
     const char* kl = smem + st * STAGE;
     const char* vl = kl + TILE;
     const int32_t tbase = tile * KT;
@@ -696,12 +710,12 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
 #undef X32_EXP
 #undef X32_STEP
     }
-    if (has_next) X32_STAGE_WRITE(st ^ 1);
+    X32_STAGE_WAIT();      // this wave's pieces of the next tile have landed; the barrier publishes everybody's
     __syncthreads();
   }
-#undef X32_LOAD_ONE
-#undef X32_STAGE_LOAD
-#undef X32_STAGE_WRITE
+#undef X32_DMA_ONE
+#undef X32_STAGE_DMA
+#undef X32_STAGE_WAIT
 
   // ---- epilogue: lane holds O[row r][d = 32 db + (i & 3) + 8 (i >> 2) + 4 h].  The wave's 32 x 128 outputs go through
   // 8 KiB of the (free) stage buffers and leave as whole 256-byte head rows, 4 rows per non-temporal store instruction;
@@ -799,6 +813,7 @@ static bool try_launch_extend32(const ExtendParams& p, int64_t batch, int64_t ma
   if (!enable || max_extend_len < 64 || p.custom_mask || p.sliding_window > 0 || p.logit_cap > 0.f || p.num_splits != 1)
     return false;
   if (p.stride_o_tok % 8 != 0 || ((uintptr_t)p.o & 15) != 0) return false;     // its 16-byte output stores
+  if (p.stride_kx_tok >= (1 << 23) || p.stride_vx_tok >= (1 << 23)) return false;   // 32-bit lane offsets of its LDS-DMA
   const int g = p.group;
 #define X32(HGV, NWV)                                                                                                     \
   {                                                                                                                       \
