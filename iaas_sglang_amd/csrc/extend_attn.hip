@@ -407,6 +407,11 @@ template <typename T> __device__ __forceinline__ uint32_t pack2_fast(float a, fl
   }
 }
 
+// max of three scores (MFMA outputs or -inf, never NaN).  Through HIP's fmaxf every score first passed a canonicalising
+// v_max_f32 x, x, x and no v_max3_f32 was formed: 104 + 17 max instructions per tile and wave in a loop whose VALU is the
+// bound; the builtin (llvm.maxnum) gives 20 + 31.
+__device__ __forceinline__ float x32_fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 template <typename T, int HG, int NW>   // NW waves per workgroup: 8 (128-key tiles, one workgroup per CU) or 4 (64-key tiles, two)
 __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendParams p, int nqb, int nreq) {
   constexpr int D = 128, KT = 16 * NW, ROWB = 256;   // four staging passes of NW * 4 key rows
@@ -605,13 +610,16 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     if (wave_active && tbase < wave_keys) {
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       f32x16 sA, sB;
+      const f32x16 x32_zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       uint4 kq[4];
       s16x4 vq_lo[4], vq_hi[4];
       uint32_t pw[2][4];
       float tmx, nmsafe;
-#define X32_MFMA(A_, B_, C_)                                                             \
-  if constexpr (__is_same(T, bf16_t)) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0); \
-  else C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
+      // D_ = A_ . B_ + C_; the first MFMA of a score chain takes the constant zero as C (an inline operand: the 16
+      // v_mov per chain that zeroed the accumulator -- ~40 VALU slots per tile and wave -- are gone)
+#define X32_MFMA(A_, B_, C_, D_)                                                         \
+  if constexpr (__is_same(T, bf16_t)) D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0); \
+  else D_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
 #define X32_KREAD(sub_, kk_) (*(const uint4*)(kl + 256 * 32 * (sub_) + kofs[kk_]))
 #define X32_VREAD(sub_, s2_, db_)                                                                                       \
   {                                                                                                                     \
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                           \
       if constexpr (more_) {                                                                     \
         const vec8 kf_ = __builtin_bit_cast(vec8, kq[kk & 3]);                                   \
-        X32_MFMA(kf_, qf[kk], NXT_);                                                             \
+        if (kk == 0) { X32_MFMA(kf_, qf[kk], x32_zero, NXT_); } else { X32_MFMA(kf_, qf[kk], NXT_, NXT_); } \
         if (kk + 4 < 8) kq[kk & 3] = X32_KREAD((sub_) + 1, kk + 4);                              \
       }                                                                                          \
       if (kk >= 4) X32_VREAD(sub_, 0, kk - 4);                                                   \
@@ -670,36 +678,31 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     _Pragma("unroll") for (int n = 0; n < 8; ++n) {                                              \
       const vec8 pf_ = __builtin_bit_cast(vec8, u32x4{pw[n >> 2][0], pw[n >> 2][1], pw[n >> 2][2], pw[n >> 2][3]}); \
       const s16x8 both_ = __builtin_shufflevector(vq_lo[n & 3], vq_hi[n & 3], 0, 1, 2, 3, 4, 5, 6, 7); \
-      X32_MFMA(__builtin_bit_cast(vec8, both_), pf_, acc[n & 3]);                                \
+      X32_MFMA(__builtin_bit_cast(vec8, both_), pf_, acc[n & 3], acc[n & 3]);                    \
       if (n < 4) X32_VREAD(sub_, 1, n)                                                           \
       else if constexpr ((sub_) + 2 < KT / 32) kq[n & 3] = X32_KREAD((sub_) + 2, n & 3);         \
-      if constexpr (more_) tmx = fmaxf(tmx, fmaxf(NXT_[2 * n], NXT_[2 * n + 1]));                \
+      if constexpr (more_) tmx = x32_fmax3(tmx, NXT_[2 * n], NXT_[2 * n + 1]);                   \
     }                                                                                            \
     if constexpr (more_) X32_DECIDE();                                                           \
   }
       // ---- prologue: S of sub-tile 0 (plain), its mask / max / decision; K fragments of sub-tile 1
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { sA[i] = 0.f; sB[i] = 0.f; }
-#pragma unroll
       for (int kk = 0; kk < 4; ++kk) kq[kk] = X32_KREAD(0, kk);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const vec8 kf = __builtin_bit_cast(vec8, kq[kk & 3]);
-        X32_MFMA(kf, qf[kk], sA);
+        if (kk == 0) { X32_MFMA(kf, qf[kk], x32_zero, sA); } else { X32_MFMA(kf, qf[kk], sA, sA); }
         if (kk + 4 < 8) kq[kk & 3] = X32_KREAD(0, kk + 4);
         else kq[kk & 3] = X32_KREAD(1, kk & 3);
       }
       X32_MASK(0, sA);
-      tmx = fmaxf(fmaxf(sA[0], sA[1]), fmaxf(sA[2], sA[3]));
+      tmx = x32_fmax3(x32_fmax3(sA[0], sA[1], sA[2]), sA[3], sA[4]);
 #pragma unroll
-      for (int i = 4; i < 16; i += 4) tmx = fmaxf(tmx, fmaxf(fmaxf(sA[i], sA[i + 1]), fmaxf(sA[i + 2], sA[i + 3])));
+      for (int i = 5; i < 15; i += 2) tmx = x32_fmax3(tmx, sA[i], sA[i + 1]);
+      tmx = x32_fmax3(tmx, sA[15], sA[15]);
       X32_DECIDE();
       X32_STEP(0, sA, sB);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sA[i] = 0.f;
       X32_STEP(1, sB, sA);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sB[i] = 0.f;
       X32_STEP(2, sA, sB);
       X32_STEP(3, sB, sA);
 #undef X32_MFMA
