@@ -424,6 +424,9 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4): the younger wave of
+  // every SIMD loses the issue arbitration on every segment otherwise
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   const int r = lane & 31, h = lane >> 5;
   const int hgroups = p.group / HG;
   // Items = (q block, head group, request), numbered q-block-MAJOR with the blocks that see the most keys first: the
