@@ -511,10 +511,27 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     glds16((in_pool_ ? (const T*)p.v_buf : (const T*)p.v_ext) + vo_,                                                \
            lds_piece + (uint32_t)((st_) * STAGE + TILE + (ps_) * RP * ROWB));                                       \
   }
+  // a tile wholly inside the cached prefix: one index (or page) lookup + one 64-bit multiply-add per row, without the
+  // clamp and the prefix / new-token selects of the general form
+#define X32_DMA_POOL(tile_, st_, ps_)                                                                               \
+  {                                                                                                                 \
+    const int32_t kp_ = (tile_) * KT + RP * (ps_) + srow;                                                           \
+    const int64_t slot_ = pshift == 0 ? (int64_t)p.kv_indices[kv_base + kp_]                                        \
+        : ((int64_t)p.page_indices[pg_base + (kp_ >> pshift)] << pshift) + (kp_ & ((1 << pshift) - 1));             \
+    glds16((const T*)p.k_buf + slot_ * p.stride_k_slot + hd_off,                                                    \
+           lds_piece + (uint32_t)((st_) * STAGE + (ps_) * RP * ROWB));                                              \
+    glds16((const T*)p.v_buf + slot_ * p.stride_v_slot + hd_off,                                                    \
+           lds_piece + (uint32_t)((st_) * STAGE + TILE + (ps_) * RP * ROWB));                                       \
+  }
 #define X32_STAGE_DMA(tile_, st_)                                                                                   \
   {                                                                                                                 \
     const int32_t t0_ = (tile_) * KT;                                                                               \
-    if (t0_ >= prefix && t0_ + KT <= n_keys) {        /* wave-uniform: scalars only */                              \
+    if (t0_ + KT <= prefix) {                         /* wave-uniform */                                            \
+      X32_DMA_POOL(tile_, st_, 0);                                                                                  \
+      X32_DMA_POOL(tile_, st_, 1);                                                                                  \
+      X32_DMA_POOL(tile_, st_, 2);                                                                                  \
+      X32_DMA_POOL(tile_, st_, 3);                                                                                  \
+    } else if (t0_ >= prefix && t0_ + KT <= n_keys) {        /* wave-uniform: scalars only */                       \
       const uint8_t* kb_ = uniform_ptr((const T*)p.k_ext + (int64_t)(q_start + t0_ - prefix) * p.stride_kx_tok);     \
       const uint8_t* vb_ = uniform_ptr((const T*)p.v_ext + (int64_t)(q_start + t0_ - prefix) * p.stride_vx_tok);     \
       _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                            \
@@ -720,6 +737,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     __syncthreads();
   }
 #undef X32_DMA_ONE
+#undef X32_DMA_POOL
 #undef X32_STAGE_DMA
 #undef X32_STAGE_WAIT
 
