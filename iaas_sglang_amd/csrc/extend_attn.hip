@@ -1045,7 +1045,8 @@ extern "C" int mi_extend_attn_fp8out(const void* q_ext, const void* k_ext, const
   MI_CHECK_ARG((page_indptr == nullptr) == (page_indices == nullptr));
   static const int enable32 = mi_tune("MI_EXTEND_32", 1);
   const bool fused = enable32 && head_dim == 128 && max_extend_len >= 64 && sliding_window <= 0 && !(logit_cap > 0.f) &&
-                     stride_o_tok % 8 == 0 && ((uintptr_t)o_ext & 15) == 0;
+                     stride_o_tok % 8 == 0 && ((uintptr_t)o_ext & 15) == 0 && stride_kx_tok < (1 << 23) &&
+                     stride_vx_tok < (1 << 23);      // (the preconditions of try_launch_extend32)
   if (fused)
     return extend_attn_impl(q_ext, k_ext, v_ext, o_ext, k_buf, v_buf, qo_indptr, kv_indptr, kv_indices, batch,
                             max_extend_len, num_q_heads, num_kv_heads, head_dim, stride_q_tok, stride_o_tok, stride_kx_tok,
