@@ -1071,3 +1071,27 @@ def test_extend_q_rotation_on_load_is_bit_identical_to_rope_then_extend(dtype, p
     assert torch.equal(o8.view(torch.uint8), ref8.view(torch.uint8))
     assert torch.equal(o.view(torch.int16), ref.view(torch.int16))
     assert not torch.equal(q.view(torch.int16), q_rot.view(torch.int16))
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (4, 2), (3, 3), (16, 2)])       # GQA 8 (70B per rank at TP = 8), 2, MHA, 8
+def test_extend_fused_prefill_forms_other_head_geometries(Hq, Hkv):
+    """fp8 output + Q rotation on load of the long-extend kernel at the head groupings its launch distinguishes (8 / 4 / 2 /
+    1 q heads per kv head and workgroup): against rope on q + mi_extend_attn + static quant, bit for bit."""
+    from iaas_sglang_amd import harness as H, ops
+    pre, ext, page_size, dtype = [300, 0, 64], [200, 700, 65], 16, torch.bfloat16
+    g = torch.Generator().manual_seed(Hq * 10 + Hkv)
+    q, kn, vn, kc, vc, qop, kvp, idx, pi, px = _paged_prefix_case(g, pre, ext, page_size, Hq=Hq, Hkv=Hkv)
+    E, _, D = q.shape
+    cache = H.rope_cache(D, 4096, 10000.0, DEV)
+    pos = torch.cat([torch.arange(p, p + e) for p, e in zip(pre, ext)]).to(DEV)
+    scale = torch.tensor([0.02], dtype=torch.float32, device=DEV)
+    q_rot, k_dummy = q.clone(), kn.clone()
+    ops.rope_neox_(q_rot.view(E, Hq * D), k_dummy.view(E, -1), pos, cache, D)
+    ref = torch.empty_like(q)
+    ops.extend_attention(q_rot, kn, vn, ref, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1)
+    ref8, _ = ops.fp8_quant_per_tensor(ref.view(E, Hq * D), scale)
+    o8 = torch.full((E, Hq * D), 0x7f, dtype=torch.uint8, device=DEV).view(ops.FP8_DTYPE)
+    ops.extend_attention_fp8out(q, kn, vn, o8, scale, kc, vc, qop, kvp, idx, max(ext), D ** -0.5, 0.0, True, -1,
+                                q_positions=pos, cos_sin_cache_t=cache.to(dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(o8.view(torch.uint8), ref8.view(torch.uint8))
