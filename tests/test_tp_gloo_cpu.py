@@ -36,7 +36,7 @@ def _worker(rank, world, port, out):
     logits = par.tensor_model_parallel_all_gather(y @ w_lm[v0:v1].t(), world, None)
     full = ((x @ w_up.t()) @ w_down.t()) @ w_lm.t()
     ok = torch.allclose(logits, full, rtol=1e-10, atol=1e-10)
-    ok = ok and sz == dict(q_heads=4, kv_heads=1, intermediate=I // 2, vocab=V // 2)
+    ok = ok and sz == dict(q_heads=8 // world, kv_heads=1, intermediate=I // world, vocab=V // world)
     t = par.max_over_ranks(1.0 + rank, world, "cpu")
     ok = ok and t == float(world)
     out[rank] = bool(ok)
@@ -45,6 +45,16 @@ def _worker(rank, world, port, out):
 
 def test_tp2_gloo():
     world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_tp8_gloo():
+    """The same exchange pattern with eight ranks (the driver's N = 8 scaling run; kv heads replicated: 2 kv heads on 8
+    ranks).  A one-GPU box admits at most 6 processes on its card, so world 8 can only be rehearsed here, on the CPU."""
+    world = 8
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
