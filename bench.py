@@ -291,7 +291,7 @@ def prefill_leg(H, stack, runner, backend, shape, nseq, S, dev, world, chunk=16)
                          "peak": round(flops / ideal / 1e12, 1), "unit": "TFLOP/s",
                          "frac": round(ideal / sec, 4),
                          "note": "peak = flops / (fp8 linear flops at 5 PF + bf16 attention and lm_head flops at 2.5 PF per GPU)"},
-            "sample": f"{nseq} sequences x {S} tokens = the metric's batch, no prefix, {shape.layers} layers, eager, "
+            "sample": f"{nseq} sequences x {S} tokens{' = the metric' + chr(39) + 's batch' if nseq == 128 and S == 2048 else ' (a SAMPLE of the metric' + chr(39) + 's 128 x 2048 batch)'}, no prefix, {shape.layers} layers, eager, "
                       f"{len(chunks)} DISTINCT EXTEND batches of {chunk} sequences (own request rows, pool slots and activations); "
                       f"flops = linears {lin:.3e} + causal attention {attn:.3e} + lm_head {head:.3e}"}
 
