@@ -407,6 +407,24 @@ template <typename T> __device__ __forceinline__ uint32_t pack2_fast(float a, fl
   }
 }
 
+#ifdef MI_TUNING
+// diagnostic (tools/x32_stamps.py): cycles of wave 0, summed over work items: [0] items, [1] entry -> Q / first-tile
+// requests issued, [2] -> first tile landed (barrier passed), [3] -> key-tile loop done, [4] -> outputs stored,
+// [5] key tiles walked, [6] -> end-of-item barrier passed
+__device__ unsigned long long mi_x32_stamps[8];
+extern "C" int mi_debug_x32_stamps(unsigned long long* host_out, int reset) {
+  if (reset) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(mi_x32_stamps)) != hipSuccess) return -1;
+    return hipMemset(d, 0, sizeof(mi_x32_stamps)) == hipSuccess ? 0 : -1;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mi_x32_stamps), sizeof(mi_x32_stamps)) == hipSuccess ? 0 : -1;
+}
+#define X32_STAMP(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
+#else
+#define X32_STAMP(var_)
+#endif
+
 // max of three scores (MFMA outputs or -inf, never NaN).  Through HIP's fmaxf every score first passed a canonicalising
 // v_max_f32 x, x, x and no v_max3_f32 was formed: 104 + 17 max instructions per tile and wave in a loop whose VALU is the
 // bound; the builtin (llvm.maxnum) gives 20 + 31.
@@ -449,6 +467,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   const int32_t kv_base = p.kv_indptr[req];
   const int32_t prefix = p.kv_indptr[req + 1] - kv_base;
   if (qb * BQ >= ext_len) continue;     // whole workgroup, before any barrier of this item
+  X32_STAMP(ts0);
 
   const int head = hk * p.group + hg * HG + (wave % HG);
   const int tok0 = qb * BQ + (wave / HG) * 32;
@@ -603,8 +622,10 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
     }
   }
 
+  X32_STAMP(ts1);
   X32_STAGE_WAIT();
   __syncthreads();
+  X32_STAMP(ts2);
 
   for (int32_t tile = 0; tile < n_tiles; ++tile) {
     const int st = tile & 1;
@@ -745,9 +766,17 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   // 8 KiB of the (free) stage buffers and leave as whole 256-byte head rows, 4 rows per non-temporal store instruction;
   // straight from the MFMA layout it was 16 stores of 32 rows x 16 B each (partial lines: the pattern that cost the
   // tile GEMM a third of its time).  LDS image: [32 rows][256 B], 16-byte chunk c of row R at position c ^ (R & 15).
+  X32_STAMP(ts3);
   lsum += __shfl_xor(lsum, 32);
   if (wave_active) {
     const float inv = 1.f / lsum;
+    // The 16 staging addresses below are lane constants: hipcc hoisted them to kernel entry, spilled them around the
+    // tile loop (256-VGPR cap) and reloaded each one from SCRATCH behind an `s_waitcnt vmcnt(0)` right here -- 16
+    // dependent memory round trips, 17 % of a 2048-token work item (in-kernel stamps, tools/x32_stamps.py).  Derived
+    // from an opaque copy of the lane's row they are recomputed after the loop (three VALU each).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r = lane_e & 31, h = lane_e >> 5;
     char* stg = smem + wave * 8192;
     typedef __attribute__((ext_vector_type(4))) uint32_t st_u32x4;
     if (p.o) {
@@ -758,7 +787,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
           *(uint2*)(stg + 256 * r + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) =
               make_uint2(pack2<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv),
                          pack2<T>(acc[db][4 * g + 2] * inv, acc[db][4 * g + 3] * inv));
-      const int pr = lane >> 4, pc = lane & 15;
+      const int pr = lane_e >> 4, pc = lane_e & 15;
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 4 + pr;
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
           *(uint32_t*)(stg + 144 * r + 32 * db + 8 * g + 4 * h) =
               x_quant4_static<T>(acc[db][4 * g] * inv, acc[db][4 * g + 1] * inv, acc[db][4 * g + 2] * inv,
                                  acc[db][4 * g + 3] * inv, qinv);
-      const int qr = lane >> 3, qc = lane & 7;
+      const int qr = lane_e >> 3, qc = lane_e & 7;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const int row = ps * 8 + qr;
@@ -793,7 +822,16 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
       }
     }
   }
+  X32_STAMP(ts4);
   __syncthreads();     // the staged outputs have been read: the next item may fill the stage buffers
+#ifdef MI_TUNING
+  if (tid == 0) {
+    const unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&mi_x32_stamps[0], 1ull); atomicAdd(&mi_x32_stamps[1], ts1 - ts0); atomicAdd(&mi_x32_stamps[2], ts2 - ts1);
+    atomicAdd(&mi_x32_stamps[3], ts3 - ts2); atomicAdd(&mi_x32_stamps[4], ts4 - ts3); atomicAdd(&mi_x32_stamps[5], (unsigned long long)n_tiles);
+    atomicAdd(&mi_x32_stamps[6], ts5 - ts4);
+  }
+#endif
   }   // items of this workgroup
 }
 
