@@ -457,15 +457,30 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   const int per_level = gy * nreq;
   const int total = nqb * per_level;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
-  const int qb = nqb - 1 - item / per_level;
+  // (the item's coordinates come out of integer divisions, i.e. in VGPRs; forced back into SGPRs so that the four
+  // indptr reads below are scalar loads issued together -- as vector loads each one was waited for in turn, three
+  // dependent memory round trips in front of every work item: in-kernel stamps, tools/x32_stamps.py)
+  const int qb = __builtin_amdgcn_readfirstlane(nqb - 1 - item / per_level);
   const int rem = item % per_level;
   const int by = rem % gy;
-  const int hk = by / hgroups, hg = by % hgroups;
-  const int req = rem / gy;
-  const int32_t q_start = p.qo_indptr[req];
-  const int32_t ext_len = p.qo_indptr[req + 1] - q_start;
-  const int32_t kv_base = p.kv_indptr[req];
-  const int32_t prefix = p.kv_indptr[req + 1] - kv_base;
+  const int hk = __builtin_amdgcn_readfirstlane(by / hgroups), hg = __builtin_amdgcn_readfirstlane(by % hgroups);
+  const int req = __builtin_amdgcn_readfirstlane(rem / gy);
+  // qo_indptr[req], [req + 1], kv_indptr[req], [req + 1] and page_indptr[req] in ONE vector load (lanes 0..4 read one
+  // word each, handed out by v_readlane): written as five reads they were two or three dependent round trips
+  const int pshift = p.page_shift;
+  int32_t meta;
+  {
+    int lp = lane;
+    asm volatile("" : "+v"(lp));     // (keeps the lane-dependent pointer below from being hoisted to kernel entry and spilled)
+    const int32_t* src = lp < 2 ? p.qo_indptr + req + lp : lp < 4 ? p.kv_indptr + req + (lp - 2)
+                                                         : (pshift ? p.page_indptr + req : p.kv_indptr + req);
+    meta = lp < 5 ? *src : 0;
+  }
+  const int32_t q_start = __builtin_amdgcn_readlane(meta, 0);
+  const int32_t ext_len = __builtin_amdgcn_readlane(meta, 1) - q_start;
+  const int32_t kv_base = __builtin_amdgcn_readlane(meta, 2);
+  const int32_t prefix = __builtin_amdgcn_readlane(meta, 3) - kv_base;
+  const int32_t pg_base = pshift ? __builtin_amdgcn_readlane(meta, 4) : 0;
   if (qb * BQ >= ext_len) continue;     // whole workgroup, before any barrier of this item
   X32_STAMP(ts0);
 
@@ -478,7 +493,9 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   // Q fragments (B operand of S^T = K . Q^T): lane -> query row r, dims 16 kk + 8 h .. + 8
   vec8 qf[8];
   // (requested with the Q rows: back by the time the first K / V tile's loads have been issued, see the rotation below)
-  const int64_t rope_pos = p.q_rope_t ? p.q_positions[q_start + my_tok] : 0;
+  // (unconditional: inside a branch the load was waited for on the spot, a round trip in front of the Q loads; without
+  // rope it reads two words of kv_indptr, which has at least two)
+  const int64_t rope_pos = *(p.q_rope_t ? p.q_positions + q_start + my_tok : (const int64_t*)p.kv_indptr);
   {
     const T* qp = (const T*)p.q + (int64_t)(q_start + my_tok) * p.stride_q_tok + (int64_t)head * D + 8 * h;
 #pragma unroll
@@ -490,8 +507,6 @@ __global__ __launch_bounds__(NW * 64) void extend_attn32_kernel(const ExtendPara
   const int32_t n_keys = prefix + (causal ? blk_last : ext_len);
   const int32_t n_tiles = (n_keys + KT - 1) / KT;
   const int32_t wave_keys = causal ? prefix + min(ext_len, tok0 + 32) : n_keys;   // keys this wave can see (exclusive)
-  const int pshift = p.page_shift;
-  const int32_t pg_base = pshift ? p.page_indptr[req] : 0;
 
   // ---- staging by LDS-DMA (round 3; was: 8 register loads + 8 ds_write_b128 per thread and tile, 32 VGPRs of a kernel
   // that sits at the 256-VGPR cap).  Wave w fills rows RP * ps + 4 w .. + 3 of both tiles with ONE 1-KiB piece per
