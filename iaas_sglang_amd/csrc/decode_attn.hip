@@ -622,6 +622,9 @@ static int decode_attn_impl(const void* q, const void* k_buf, const void* v_buf,
   if (num_splits > 1) {
     const int64_t n_bh = batch * num_q_heads;
     const unsigned blocks = (unsigned)cdiv64(n_bh, 4);
+    // without a work list every (request, split) workgroup ran and wrote its (m, l) -- empty splits l = 0 -- so the
+    // merge need not derive the live splits from kv_indptr (a dependent load in front of its first read)
+    if (!p.work) kv_indptr = nullptr;
     if (dtype == MI_BF16) {
       if (head_dim == 128)
         decode_merge_kernel<bf16_t, 128><<<blocks, 256, 0, st>>>(p.ws_o, p.ws_ml, (bf16_t*)o, n_bh, p.num_q_heads, p.num_splits, stride_o_tok, p.o_q, p.o_qscale, p.v_scale, kv_indptr, p.split_chunk, p.plan);
