@@ -1421,6 +1421,9 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
   TileAddr cur, nxt;
   if (slot < xcnt) tile_addr(slot, cur);
   for (int li = slot; li < xcnt; li += gx) {
+#ifdef MI_TUNING
+  const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+#endif
   const bool more = li + gx < xcnt;
   // the next tile's first stage lands during this tile's epilogue (which only uses the other stage buffer); the last
   // tile's last k-step requests its own first stage again (never read): the loop body stays one basic block
@@ -1487,11 +1490,25 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       const uint4 a0 = TL_FRAG(wb, row, q), a1 = TL_FRAG(wb, row, 4 + q);
       wf[j] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
     }
+    // activation fragments one m-tile AHEAD in a second register set: read right after the MFMAs of m-tile i were
+    // issued and waited for in front of the MFMAs of i + 1, a fragment had 128 cycles (4 MFMAs) to arrive -- with the
+    // CU's LDS half busy (192 KiB of fragment reads per k-step) it took longer, ~100 exposed cycles per m-tile
+    // (tools/tile_stamps.py: 3160 cycles per k-step for 2048 of MFMA)
+    i32x8 xfb[2];
+    {
+      const int row = wm * 128 + r16;
+      const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
+      xfb[0] = i32x8{(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = wm * 128 + i * 16 + r16;
-      const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
-      const i32x8 xf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+      if (i + 1 < 8) {
+        const int row = wm * 128 + (i + 1) * 16 + r16;
+        const uint4 b0 = TL_FRAG(xb, row, q), b1 = TL_FRAG(xb, row, 4 + q);
+        xfb[(i + 1) & 1] = i32x8{(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the read back behind this m-tile's MFMAs)
+      const i32x8 xf = xfb[i & 1];
       if (i < 2) {
         glds16_s(__umul24((uint32_t)min(prow[2 * i], xcl), lda32) + (uint32_t)pslot[2 * i], xs, xdst + (2 * i) * 1024);
         glds16_s(__umul24((uint32_t)min(prow[2 * i + 1], xcl), lda32) + (uint32_t)pslot[2 * i + 1], xs, xdst + (2 * i + 1) * 1024);
@@ -1509,6 +1526,9 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     __syncthreads();
   }
   first_issued = ahead;
+#ifdef MI_TUNING
+  const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
+#endif
   // the activation stage and the weight stage of the last k-step are free for the epilogue (32 KiB each; the others
   // hold or are receiving the next tile's first k-steps): waves 0..3 use the one, waves 4..7 the other
   char* const free_x = smem + TL_XST(step - 1);
@@ -1589,7 +1609,9 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
           *(uint32_t*)(stg + row * 128 + ((((wn & 1) * 4 + j) ^ (row & 7)) << 4) + q * 4) = wq[ii][j];
         }
       __syncthreads();
-      const int pr = lane >> 3, pc = lane & 7;
+      int lane_e = lane;                     // (opaque: see the plain epilogue below)
+      asm volatile("" : "+v"(lane_e));
+      const int pr = lane_e >> 3, pc = lane_e & 7;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {       // the four waves of this half take 32 rows each
         const int row = wn * 32 + ps * 8 + pr;
@@ -1638,7 +1660,11 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     // 1.21 ms, persistent with these stores 1.23 ms).  LDS image: [64 rows][128 B], 16-byte chunk c of row R at
     // position c ^ (R & 7) (the 8-byte writes of the MFMA layout then spread over all banks).
     char* stg = (wave < 4 ? free_x : free_w) + (wave & 3) * 8192;
-    const int pr = lane >> 3, pc = lane & 7;
+    // (an opaque copy of the lane id: the lane-constant parts of the store addresses below are then computed here
+    // instead of being hoisted to kernel entry, spilled around the k-loop and reloaded from scratch per tile)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int pr = lane_e >> 3, pc = lane_e & 7;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float sav[4];
@@ -1703,7 +1729,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     }
   }
   // every wave is done with the LDS of this tile (staging reads included) before the next tile requests into it
+#ifdef MI_TUNING
+  const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef MI_TUNING
+  if (lane == 0 && blockIdx.x < 512) {     // tools/tile_stamps.py: k-loop / epilogue / end barrier ticks per wave, tiles
+    unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+    o[0] += tt1 - tt0; o[1] += tt2 - tt1; o[2] += __builtin_amdgcn_s_memtime() - tt2; o[3] += 1;
+  }
+#endif
   cur = nxt;
   }   // tiles of this workgroup
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // the last prefetch has landed: its register is free again
