@@ -1467,7 +1467,13 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+#ifdef MI_TUNING
+  unsigned long long ks_issue = 0, ks_vm = 0, ks_bar = 0;
+#endif
   for (int64_t kt = kt0; kt < KT; ++kt, ++step) {
+#ifdef MI_TUNING
+    const unsigned long long ks0 = __builtin_amdgcn_s_memtime();
+#endif
     // the requests are placed piece by piece BETWEEN the first MFMA groups: both waves of a SIMD leave the barrier
     // together, and with all eight requests up front they spent ~0.3 us issuing DMAs side by side before the first
     // MFMA -- now one wave's requests run under the other's (and its own) MFMAs.  A wave requests its 4 activation
@@ -1522,9 +1528,24 @@ __global__ __launch_bounds__(512) void fp8_gemm_tile_kernel(const GemmParams p, 
       if (i == 3)   // `pf_sink` is tied in and out: its register stays reserved for the whole loop (the load lands late)
         asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_off), "s"(pf_base + min(kt + PF, KT - 1) * BK) : "memory");
     }
+#ifdef MI_TUNING
+    const unsigned long long ks1 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // all but the 4 weight pieces and the prefetch just issued
+#ifdef MI_TUNING
+    const unsigned long long ks2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef MI_TUNING
+    { const unsigned long long ks3 = __builtin_amdgcn_s_memtime(); ks_issue += ks1 - ks0; ks_vm += ks2 - ks1; ks_bar += ks3 - ks2; }
+#endif
   }
+#ifdef MI_TUNING
+  if (lane == 0 && blockIdx.x < 512) {     // per k-step: reads + MFMA issue / DMA wait / barrier, and the k-steps counted
+    unsigned long long* o = mi_xd_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+    o[4] += ks_issue; o[5] += ks_vm; o[6] += ks_bar; o[7] += (unsigned long long)(KT - kt0);
+  }
+#endif
   first_issued = ahead;
 #ifdef MI_TUNING
   const unsigned long long tt1 = __builtin_amdgcn_s_memtime();

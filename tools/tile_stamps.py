@@ -36,3 +36,6 @@ for N, K in [(6144, 4096), (4096, 4096), (4096, 14336)]:
           f"({float(t[:, :8, 0].sum() / tiles) / (K // 128):.0f} per k-step), epilogue {float(t[:, :8, 1].sum() / tiles):.0f}, "
           f"end barrier {float(t[:, :8, 2].sum() / tiles):.0f} ticks; by wave epilogue: "
           + " ".join(f"{float(t[:, wv, 1].sum() / t[:, wv, 3].sum().clamp(min=1)):.0f}" for wv in range(8)), flush=True)
+    ks = t[:, :8, 7].sum()
+    print("   per k-step and wave: reads + MFMA issue " + " ".join(f"{float(t[:, wv, 4].sum() / t[:, wv, 7].sum().clamp(min=1)):.0f}" for wv in range(8))
+          + f" | DMA wait {float(t[:, :8, 5].sum() / ks):.0f} | barrier " + " ".join(f"{float(t[:, wv, 6].sum() / t[:, wv, 7].sum().clamp(min=1)):.0f}" for wv in range(8)), flush=True)
